@@ -1,0 +1,184 @@
+/*
+ * ucf.h -- C ABI of the MI355X-native Laplace-Hankel drawdown engine.
+ *
+ * This is the drop-in boundary for the one hot path of klkuhlm/unconfined: the
+ * per-(t,r) loop body of `program Driver` (reference driver.f90:100-276) and the
+ * module procedures it imports (reference driver.f90:28-40).  The reference has
+ * no FFI for this path (its only ISO_C_BINDING precedent is arb_J/arb_Y,
+ * reference laplace_hankel_solutions.f90:310-325: scalars by value, plain
+ * numbers); every entry point below therefore names the reference procedure or
+ * loop it replaces.  A reference-side binding (Fortran `bind(C)` interface block)
+ * is shown in INTEGRATION.md and shipped in unconfined_amd/fortran/.
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, caller-owned contiguous fp64 / int32 arrays;
+ *   - complex vectors travel as interleaved (re,im) doubles;
+ *   - every function returns UCF_OK (0) or a negative ucf_status; nothing aborts
+ *     (the reference `stop`s on bad input, driver_io.f90:78-378; we return the
+ *     matching UCF_ERR_* instead and ucf_last_error() gives the message);
+ *   - "in-band" numerical rules of the reference (NaN->0 scrub, Wynn-epsilon
+ *     truncation/sentinel, epsilon-table early exit, FD underflow guard) are
+ *     part of the numerical contract and are reproduced on the device;
+ *   - a plan is immutable after creation; batch calls on one plan are
+ *     re-entrant as long as each call uses its own stream/output buffers.
+ *   - there is NO CPU fallback: every compute entry point fails with
+ *     UCF_ERR_NO_DEVICE if no gfx950-capable HIP device is usable.
+ */
+#ifndef UCF_H
+#define UCF_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UCF_VERSION 100        /* 0.1.0 */
+#define UCF_MAX_MOENCH 16      /* max number of Moench alphas (driver_io.f90:142-151) */
+#define UCF_MAX_NZ 32          /* max depths per point handled by one launch */
+#define UCF_MAX_LAP_M 31       /* 2M+1 <= 64: one Laplace sample per lane of a wave */
+
+typedef enum ucf_status {
+    UCF_OK = 0,
+    UCF_ERR_INVALID_MODEL = -1,     /* driver_io.f90:90-97   */
+    UCF_ERR_GEOMETRY = -2,          /* driver_io.f90:236-258 */
+    UCF_ERR_AQUIFER = -3,           /* driver_io.f90:242-252 */
+    UCF_ERR_MISHRA_NEUMAN = -4,     /* driver_io.f90:260-276 */
+    UCF_ERR_MALAMA_BETA = -5,       /* driver_io.f90:278-281 */
+    UCF_ERR_MOENCH = -6,            /* driver_io.f90:142-149,283-290 */
+    UCF_ERR_DEHOOG = -7,            /* driver_io.f90:306-309 */
+    UCF_ERR_TANH_SINH = -8,         /* driver_io.f90:316-327 */
+    UCF_ERR_GAUSS_LOBATTO = -9,     /* driver_io.f90:329-333 */
+    UCF_ERR_UNSUPPORTED = -10,      /* valid in the reference, not built here (see ucf_last_error) */
+    UCF_ERR_BAD_ARGUMENT = -11,
+    UCF_ERR_NO_DEVICE = -12,
+    UCF_ERR_HIP = -13,
+    UCF_ERR_NOMEM = -14,
+    UCF_ERR_OBSERVATION = -15       /* driver_io.f90:352-383 */
+} ucf_status;
+
+/*
+ * POD mirror of the reference's parameter types as read from the 18-line deck
+ * (types.f90:31-225: well, formation, solution, invLaplace, TanhSinh,
+ * invHankel, GaussLobatto).  Dimensional quantities, exactly as on the deck;
+ * non-dimensionalisation (driver_io.f90:531-567) happens in ucf_plan_create.
+ */
+typedef struct ucf_params {
+    int model;            /* 0 Theis, 1 Hantush, 2 Hantush+storage, 3 Moench, 4 Malama full, 5 Malama partial, 6 Mishra/Neuman */
+    int MNtype;           /* model 6: 0 naive (ARB, unsupported), 1 Malama, 2 finite difference */
+    int order;            /* model 6 / MNtype 2: FD nodes in the vadose zone */
+    int timeType;         /* pumping-rate time behaviour (time.f90:46); this build: 1..6,8 */
+    double timePar[2];
+    double Q;             /* pumping rate [L^3/T] */
+    double l, d;          /* depth to screen bottom / top from aquifer top [L] */
+    double rw, rc;        /* well / casing radius [L] */
+    double gammaSkin;
+    double b;             /* saturated thickness [L] */
+    double Kr, kappa;     /* radial K [L/T], Kz/Kr */
+    double Ss, Sy;
+    double beta;          /* Malama linearisation parameter */
+    int MoenchM;
+    int _pad0;
+    double MoenchAlpha[UCF_MAX_MOENCH];
+    double ac, ak, psia, psik, usL;   /* Mishra/Neuman vadose-zone parameters */
+    int M;                /* de Hoog: 2M+1 Laplace samples */
+    int k;                /* tanh-sinh: N = 2^k - 1 abscissae */
+    int R;                /* Richardson levels */
+    int nacc;             /* J0-zero intervals accelerated by Wynn-epsilon */
+    int ord;              /* Gauss-Lobatto order (ord-2 interior nodes) */
+    int j0s[2];           /* min/max J0 zero at which finite/infinite parts split */
+    int _pad1;
+    double alpha, tol;    /* de Hoog abscissa of convergence, tolerance */
+    double rwobs, sF;     /* observation well radius / shape factor (model 2) */
+} ucf_params;
+
+/* Derived, dimensionless quantities (driver_io.f90:531-567) -- read back for tests/headers. */
+typedef struct ucf_derived {
+    double Lc, Tc, Hc;
+    double sigma, alphaD, betaD;
+    double lD, dD, bD, rDw, rDwobs;
+    double acD, akD, lambdaD, psiaD, psikD, usLD, b1, PsiD;
+    double MoenchGamma[UCF_MAX_MOENCH];
+    double l_eff, d_eff, ac_eff;   /* after the MNtype==1 overrides (driver_io.f90:159-186) */
+    int np;       /* 2M+1 */
+    int N;        /* 2^k-1 */
+    int nj0z;     /* max(j0s)+nacc+1 */
+    int nabs;     /* N + nacc*(ord-2): abscissae per point */
+} ucf_derived;
+
+/* Counters of the in-band rules taken during a batch. */
+typedef struct ucf_stats {
+    long long nan_scrubbed;     /* invlap.f90:71-74  : NaN Laplace samples set to 0        */
+    long long zero_vectors;     /* invlap.f90:69,139 : all-zero f(p) -> f(t)=0             */
+    long long wynn_truncated;   /* integration.f90:150-158 : series cut at first non-finite */
+    long long wynn_sentinel;    /* integration.f90:142-149 : < 4 usable terms -> -999999.9  */
+    long long wynn_early_exit;  /* integration.f90:169-177 : |denom| <= 2.2e-16             */
+    long long wynn_all_zero;    /* driver.f90:209 : every area exactly 0 -> 0 (quirk Q5)   */
+} ucf_stats;
+
+typedef struct ucf_plan ucf_plan;
+
+int ucf_version(void);
+const char* ucf_last_error(void);          /* thread-local message of the last failure */
+const char* ucf_status_string(int status);
+
+/* ---- plan: replaces read_input's numerical half + the `first`-time setup in the driver
+ * (driver_io.f90:531-567,628-647; driver.f90:79-91,121-126,138-151,179-183). ---- */
+int ucf_plan_create(const ucf_params* P, ucf_plan** out);
+void ucf_plan_destroy(ucf_plan* plan);
+int ucf_plan_derived(const ucf_plan* plan, ucf_derived* out);
+int ucf_plan_j0z(const ucf_plan* plan, int n, double* j0z);             /* driver_io.f90:628-647 */
+int ucf_plan_tanh_sinh(const ucf_plan* plan, int level /*1..R*/, int n, double* w, double* x_unit /* tanh(u2)+1, level R only, may be NULL */);
+int ucf_plan_gauss_lobatto(const ucf_plan* plan, int n, double* x, double* w);
+/* execution mode: 0 = faithful (reference operation order, no FMA contraction),
+ *                 1 = fast (same algorithm, FMA contraction + shared subexpressions). */
+int ucf_plan_set_mode(ucf_plan* plan, int mode);
+
+/* ---- host-side helpers that the reference computes in read_input ---- */
+int ucf_logspace(int lo, int hi, int n, double* out);                   /* utility.f90:51-57 */
+int ucf_linspace(double lo, double hi, int n, double* out);             /* utility.f90:34-49 */
+int ucf_zlay(const ucf_plan* plan, int nz, const double* zD, int* zLay);            /* driver_io.f90:575-586 */
+int ucf_split_vector(const ucf_plan* plan, int nt, const double* tD, int* sv);      /* driver_io.f90:654-664 */
+
+/* ---- the hot path: replaces the body of the (i,k) loop nest, driver.f90:100-232.
+ * Points are independent (flattened t x r); per point: tD, rD, sv (1-based index
+ * into j0z).  Outputs h, dh are dimensionless, [npts][nz] row-major, *before* the
+ * screen averaging of driver.f90:234-243 (see ucf_screen_average). ---- */
+int ucf_drawdown_batch(ucf_plan* plan, int npts,
+                       const double* tD, const double* rD, const int* sv,
+                       int nz, const double* zD, const int* zLay,
+                       double* h, double* dh, ucf_stats* stats /* may be NULL */);
+
+/* Same, all per-point arrays already resident in HBM; asynchronous on `stream`
+ * (a hipStream_t passed as void*; NULL = default stream).  `d_stats` may be NULL. */
+int ucf_drawdown_batch_device(ucf_plan* plan, int npts,
+                              const double* d_tD, const double* d_rD, const int* d_sv,
+                              int nz, const double* zD, const int* zLay,
+                              double* d_h, double* d_dh, ucf_stats* d_stats, void* stream);
+
+/* driver.f90:234-243 (quirk Q2: not a textbook trapezoid) */
+int ucf_screen_average(int npts, int zOrd, const double* h, double* havg);
+
+/* ---- stage hooks (device implementations of the imported procedures; used by the
+ * parity tests to compare each stage with the oracle) ---- */
+/* lap_hank_soln, laplace_hankel_solutions.f90:30-120: fp[n_a][nz][np] complex */
+int ucf_eval_samples(ucf_plan* plan, int n_a, const double* a, double rD,
+                     int np, const double* p_re_im, int nz, const double* zD, const int* zLay,
+                     double* fp_re_im);
+/* deHoog_pvalues, invlap.f90:154-172 */
+int ucf_pvalues(const ucf_plan* plan, double tee, double* p_re_im);
+/* deHoog_invlap (scalar t), invlap.f90:143-152 -> 46-141; n independent problems */
+int ucf_dehoog(int n, int M, double alpha, double tol, const double* t, const double* tee,
+               const double* fp_re_im /*[n][2M+1]*/, double* ft);
+/* wynn_epsilon, integration.f90:125-189; status: 0 ok, 1 truncated, 2 sentinel, 3 early exit */
+int ucf_wynn_epsilon(int n, int nterms, const double* series_re_im /*[n][nterms]*/,
+                     double* acc_re_im, int* status);
+/* extraptozero, integration.f90:192-237 */
+int ucf_extraptozero(int n, int R, const double* x /*[R]*/, const double* y_re_im /*[n][R]*/,
+                     double* out_re_im);
+
+/* ---- measurement helper: sustained fp64 FMA rate of the device ---- */
+int ucf_fp64_fma_peak(double* tflops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UCF_H */

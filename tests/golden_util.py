@@ -1,0 +1,75 @@
+"""helpers shared by the parity tests: fixture loading and ulp / relative-error measures"""
+import json
+import os
+import struct
+
+import numpy as np
+
+from unconfined_amd.abi import params_from_deck
+from unconfined_amd.deck import Deck, TimeSpec
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+DECKS = os.path.join(GOLD, "decks")
+
+
+def deck_names():
+    return sorted(f[7:-5] for f in os.listdir(GOLD) if f.startswith("stages_") and f.endswith(".json"))
+
+
+def unhx(s):
+    return struct.unpack("<d", struct.pack("<Q", int(s, 16)))[0]
+
+
+def load_deck(name):
+    dk = Deck.read(os.path.join(DECKS, f"{name}.in"))
+    ts = TimeSpec.read(os.path.join(DECKS, dk.timeFileName))
+    return dk, ts, params_from_deck(dk)
+
+
+def load_stages(name):
+    with open(os.path.join(GOLD, f"stages_{name}.json")) as f:
+        meta = json.load(f)
+    return meta, np.load(os.path.join(GOLD, f"stages_{name}.npz"))
+
+
+def load_e2e(name):
+    p = os.path.join(GOLD, f"e2e_{name}.npz")
+    return np.load(p) if os.path.exists(p) else None
+
+
+def ulps(a, b):
+    """distance in units of last place; NaN==NaN counts as 0, NaN vs number as a huge value"""
+    a = np.ascontiguousarray(a, np.float64)
+    b = np.ascontiguousarray(b, np.float64)
+    ai = a.view(np.int64).astype(np.int64)
+    bi = b.view(np.int64).astype(np.int64)
+    ai = np.where(ai < 0, np.int64(-2 ** 63) - ai, ai)
+    bi = np.where(bi < 0, np.int64(-2 ** 63) - bi, bi)
+    d = np.abs(ai.astype(np.float64) - bi.astype(np.float64))
+    both = np.isnan(a) & np.isnan(b)
+    one = np.isnan(a) ^ np.isnan(b)
+    d = np.where(both, 0.0, d)
+    d = np.where(one, 1e30, d)
+    return d
+
+
+def bits_equal(a, b):
+    return float(ulps(a, b).max(initial=0.0)) == 0.0
+
+
+def crel(a, b, floor=0.0):
+    """relative error of complex vectors stored as [...,2] against reference b"""
+    a = np.asarray(a); b = np.asarray(b)
+    za = a[..., 0] + 1j * a[..., 1]
+    zb = b[..., 0] + 1j * b[..., 1]
+    with np.errstate(all="ignore"):
+        r = np.abs(za - zb) / np.maximum(np.abs(zb), floor if floor > 0 else 1e-300)
+    both_bad = ~np.isfinite(za) & ~np.isfinite(zb)
+    r = np.where(both_bad, 0.0, r)
+    return np.where(np.isnan(r), np.inf, r)
+
+
+def rel_err(x, ref, floor=1e-3):
+    """|x-ref| / max(|ref|, floor)  (measure iii)"""
+    x = np.asarray(x, float); ref = np.asarray(ref, float)
+    return np.abs(x - ref) / np.maximum(np.abs(ref), floor)
