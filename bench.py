@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""bench.py -- (t,r) drawdown points/s on the Neuman-1974 1024x256 sweep (BASELINE.json
+configs[1], SURVEY.md section 8d "C2"): model 5 with beta = 0, fully penetrating well,
+M = 26 (53 Laplace samples), tanh-sinh k = 6 / R = 4, 10 J0 intervals x 48 Gauss-Lobatto
+nodes => 543 abscissae, 28 779 Laplace-Hankel samples per point, fp64 throughout.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--mode faithful|fast]
+
+One "step" = one pass of the hot path over the whole synthetic sweep that is resident
+in HBM (tD, rD, split index per point in; h and dh per point out).  With N > 1 the
+driver launches this file under torch.distributed.run; the flattened (t,r) index is
+block-partitioned over ranks (weak scaling: every rank owns a full 1024x256 block of
+a 1024 x 256N sweep), no data-path collective, and each step ends with the RCCL
+all-gather of the (h, dh) results that the reference's single output file implies.
+
+The JSON line carries
+  roofline      : bound = fp64 VALU (this path is neither HBM- nor MFMA-bound);
+                  achieved = algorithmic flop per launch / average kernel duration
+                  (HIP events on the launch stream); peak = 78.6 TFLOP/s (fp64 vector,
+                  = 1/2 of the 157.3 TF fp32 vector figure of MI355X_MICROARCH.md); the
+                  measured fp64-FMA rate of this device and the HBM view are added.
+  cpu_baseline  : the reference binary itself (oracle/_ref/O2/unconfined, flang -O2,
+                  OpenMP on all host cores) when it was shipped with the repo, else the
+                  C oracle; timed on a bounded sample of the same workload, rank 0, N=1.
+"""
+import argparse
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# ---- SURVEY.md section 8d flop convention (fp64, FMA = 2): reference formulation of a model-5 sample
+FLOP_PER_SAMPLE = 1420.0
+FLOP_TAIL_PER_POINT = 0.1e6
+PEAK_FP64_VALU_TFLOPS = 78.6
+PEAK_HBM_GBS = 8000.0
+
+
+def c2_deck():
+    from unconfined_amd.deck import Deck
+    return Deck(quiet=0, model=5, dimless=False, timeseries=True, piezometer=True,
+                Q=42.8, l=160.0, d=0.0, rw=0.3333, rc=0.3333, gammaSkin=1.0, timeType=1, timePar=[0.0, 1.0],
+                b=160.0, Kr=0.24, kappa=0.4, Ss=2.9e-5, Sy=0.23, beta=0.0, MoenchM=1, MoenchAlpha=[-9999.0],
+                ac=2.9, ak=0.37, psia=2.0, psik=0.22, usL=20.0, MNtype=2, order=5,
+                M=26, alpha=1.0e-8, tol=1.0e-9, k=6, R=4, j0s=[1, 1], nacc=10, ord=50,
+                tval=9999.9, rval=85.1, zTop=146.7, zBot=144.7, zOrd=2, rwobs=0.167, sF=1.0)
+
+
+def cpu_baseline(dk, ncores):
+    """reference-equivalent CPU throughput on a bounded sample: 2 radii x 1024 times of the C2 sweep"""
+    from unconfined_amd.deck import TimeSpec
+    ref = os.path.join(ROOT, "oracle", "_ref", "O2", "unconfined")
+    radii = [160.0]
+    nt = 1024
+    if os.path.exists(ref):
+        work = tempfile.mkdtemp(prefix="ucf_cpu_")
+        try:
+            TimeSpec(True, -1, 8, nt).write(os.path.join(work, "time_c2.dat"))
+            t0 = time.time()
+            for i, r in enumerate(radii):
+                d = dk.replace(rval=r, timeFileName="time_c2.dat", spaceFileName="unused.dat", outFileName=f"c2_{i}.out")
+                d.write(os.path.join(work, f"c2_{i}.in"))
+                env = dict(os.environ, OMP_NUM_THREADS=str(ncores))
+                subprocess.run([ref, f"c2_{i}.in"], cwd=work, env=env, check=True, capture_output=True)
+            dt = time.time() - t0
+            rows = sum(1 for i in range(len(radii)) for ln in open(os.path.join(work, f"c2_{i}.out")) if not ln.startswith("#"))
+            if rows == nt * len(radii):
+                return {"value": rows / dt, "unit": "points/s", "cores": ncores, "kind": "reference",
+                        "sample": f"reference binary (flang -O2, OpenMP), C2 deck, {len(radii)} radii x {nt} times = {rows} points in {dt:.1f} s"}
+        except Exception as exc:  # fall through to the port
+            print(f"[bench] reference binary unusable here ({exc}); timing the C oracle instead", file=sys.stderr)
+        finally:
+            shutil.rmtree(work, ignore_errors=True)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_lib import Oracle
+    from unconfined_amd.abi import params_from_deck
+    O = Oracle()
+    P = params_from_deck(dk)
+    D = O.nondim(P)
+    t = O.logspace(-1, 8, nt)
+    tD = np.tile(t / D.Tc, len(radii))
+    rD = np.repeat(np.array(radii) / D.Lc, nt)
+    sv = np.ones(len(tD), np.int32)
+    zD = np.array([145.7 / D.Lc])
+    zl = O.zlay(D, zD)
+    t0 = time.time()
+    O.batch(P, tD, rD, sv, zD, zl, threads=ncores)
+    dt = time.time() - t0
+    return {"value": len(tD) / dt, "unit": "points/s", "cores": ncores, "kind": "port",
+            "sample": f"C oracle (gcc -O2, OpenMP), C2 deck, {len(radii)} radii x {nt} times = {len(tD)} points in {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--mode", default=os.environ.get("UCF_BENCH_MODE", "fast"), choices=["faithful", "fast"])
+    ap.add_argument("--nt", type=int, default=1024)
+    ap.add_argument("--nr", type=int, default=256)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the drawdown path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
+
+    from unconfined_amd import engine
+    from unconfined_amd.abi import params_from_deck
+
+    dk = c2_deck()
+    P = params_from_deck(dk)
+    plan = engine.Plan(P, mode=args.mode)
+    D = plan.derived
+
+    # ---- the sweep: 1024 log-spaced times x (256 * world) log-spaced radii, rank owns a block of 256 radii
+    nt, nr = args.nt, args.nr
+    t = engine.logspace(-1, 8, nt)
+    tD = t / D.Tc
+    sv_t = plan.split_vector(tD)
+    rD_all = 10.0 ** engine.linspace(-1.0, 1.0, nr * world)
+    rD_mine = rD_all[rank * nr:(rank + 1) * nr]
+    TT, RR = np.meshgrid(tD, rD_mine, indexing="ij")
+    SV = np.repeat(sv_t[:, None], nr, axis=1)
+    npts = nt * nr
+    zD = np.array([145.7 / D.Lc])
+    zl = plan.zlay(zD)
+    nz = 1
+
+    dev = torch.device("cuda", local_rank)
+    d_tD = torch.from_numpy(TT.ravel().copy()).to(dev)
+    d_rD = torch.from_numpy(RR.ravel().copy()).to(dev)
+    d_sv = torch.from_numpy(SV.ravel().astype(np.int32).copy()).to(dev)
+    d_out = torch.zeros(2, npts * nz, dtype=torch.float64, device=dev)       # [h; dh]
+    d_all = torch.zeros(world * 2, npts * nz, dtype=torch.float64, device=dev) if world > 1 else None
+    stream = torch.cuda.current_stream()
+
+    def step():
+        plan.drawdown_device(npts, d_tD.data_ptr(), d_rD.data_ptr(), d_sv.data_ptr(), zD, zl,
+                             d_out[0].data_ptr(), d_out[1].data_ptr(), stream=stream.cuda_stream)
+        if world > 1:
+            dist.all_gather_into_tensor(d_all, d_out)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    # kernel-only duration with HIP events on the launch stream (same K launches)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record(stream)
+        plan.drawdown_device(npts, d_tD.data_ptr(), d_rD.data_ptr(), d_sv.data_ptr(), zD, zl,
+                             d_out[0].data_ptr(), d_out[1].data_ptr(), stream=stream.cuda_stream)
+        ev[k][1].record(stream)
+        if world > 1:
+            dist.all_gather_into_tensor(d_all, d_out)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # sanity: results are finite and the gathered copy equals the local one
+    h_host = d_out[0].cpu().numpy()
+    ok = bool(np.isfinite(h_host).all())
+    if world > 1:
+        ok = ok and bool(torch.equal(d_all[2 * rank:2 * rank + 2], d_out))
+
+    if rank == 0:
+        total_pts = npts * world * args.steps
+        value = total_pts / elapsed
+        samples_per_pt = D.nabs * D.np * nz
+        flop_per_pt = FLOP_PER_SAMPLE * samples_per_pt + FLOP_TAIL_PER_POINT
+        achieved_tf = flop_per_pt * npts / (kern_ms * 1e-3) * 1e-12
+        try:
+            fma_peak = engine.fp64_fma_peak()
+        except Exception:
+            fma_peak = None
+        alg_bytes = (20 + 16 * nz) * npts
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(args.mode, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "(t,r) drawdown points/sec, Neuman-1974 1024x256 sweep",
+            "value": value, "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"C2: Neuman-1974 (model 5, beta=0) fully penetrating, {nt} log-spaced times x {nr} "
+                                   f"log-spaced radii per GPU, M=26, k=6/R=4, nacc=10, ord=50 ({D.nabs} abscissae, "
+                                   f"{samples_per_pt} samples/point)",
+                       "points_per_gpu": npts, "mode": args.mode, "partition": "contiguous (t,r) blocks, one rank per GPU",
+                       "results_finite_and_gather_consistent": ok},
+            "roofline": {"bound": "fp64_valu", "achieved": achieved_tf, "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved_tf / PEAK_FP64_VALU_TFLOPS, "traffic": traffic,
+                         "kernel_ms": kern_ms, "flop_per_point": flop_per_pt,
+                         "peak_measured_fp64_fma": fma_peak,
+                         "frac_of_measured_fma": (achieved_tf / fma_peak) if fma_peak else None,
+                         "hbm": {"algorithmic_bytes_per_launch": alg_bytes,
+                                 "achieved_GBs": alg_bytes / (kern_ms * 1e-3) * 1e-9, "peak_GBs": PEAK_HBM_GBS,
+                                 "frac": alg_bytes / (kern_ms * 1e-3) * 1e-9 / PEAK_HBM_GBS}},
+        }
+        if world == 1 and not args.no_cpu:
+            # the box shows every hardware thread of the host but a 1-GPU job owns a 16-core share; the
+            # reference's OpenMP regions are 48-63 iterations long, so more threads only add overhead
+            navail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            ncores = int(os.environ.get("UCF_CPU_THREADS", min(16, navail)))
+            line["cpu_baseline"] = cpu_baseline(dk, ncores)
+            line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

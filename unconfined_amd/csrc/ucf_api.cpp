@@ -1,0 +1,589 @@
+// ucf_api.cpp -- host side of the C ABI declared in include/ucf.h.
+//
+// Plan creation restates the numerical half of the reference's read_input and the
+// driver's `first`-time setup (reference driver_io.f90:159-186,531-567,628-647;
+// driver.f90:79-91,121-126,138-151,179-183; integration.f90:31-120) on the host:
+// these run once, their results (J0 zeros, tanh-sinh weights, Gauss-Lobatto nodes)
+// are uploaded once and stay resident.  This file is product code: it does not
+// include, link or call anything under oracle/.
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "ucf_plan.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) return fail(UCF_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+int require_device()
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(UCF_ERR_NO_DEVICE, "no HIP device available (%s); this library has no CPU fallback",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    return UCF_OK;
+}
+
+// ---- driver_io.f90:88-333: the checks read_input performs before stopping
+int validate(const ucf_params& P)
+{
+    if (P.model < 0 || P.model > 6) return fail(UCF_ERR_INVALID_MODEL, "invalid model choice %d (valid: 0..6)", P.model);
+    if (P.model == 3 && P.MoenchM < 1) return fail(UCF_ERR_MOENCH, "number of Moench alphas must be >= 1 for model 3");
+    if (P.MoenchM > UCF_MAX_MOENCH) return fail(UCF_ERR_MOENCH, "more than %d Moench alphas", UCF_MAX_MOENCH);
+    if (P.model > 0 && (P.gammaSkin < 0.0 || P.d < 0.0 || P.l < 0.0))
+        return fail(UCF_ERR_GEOMETRY, "negative geometry parameters (gamma, d, l)");
+    if (P.b <= 0.0 || P.Kr <= 0.0 || P.Ss <= 0.0) return fail(UCF_ERR_AQUIFER, "zero or negative aquifer parameters (b, Kr, Ss)");
+    if (P.model > 2 && (P.kappa <= 0.0 || P.Sy <= 0.0))
+        return fail(UCF_ERR_AQUIFER, "zero or negative unconfined aquifer parameters (kappa, Sy)");
+    double l = P.l, d = P.d;
+    if (P.MNtype == 1) {                     // overrides happen before the check in the reference (:159-186)
+        if (std::fabs(l - P.b) > FLT_EPSILON) l = P.b;
+        if (d > FLT_EPSILON) d = 0.0;
+    }
+    if (P.model > 0 && d >= l) return fail(UCF_ERR_GEOMETRY, "screen top/bottom: l must be > d (l=%g d=%g)", l, d);
+    if (P.model == 6) {
+        if (P.ac < 0.0 || P.ak < 0.0 || P.usL < 0.0 || P.psia < 0.0 || P.psik < 0.0)
+            return fail(UCF_ERR_MISHRA_NEUMAN, "invalid Mishra/Neuman parameters (a_c, a_k, L, psi_a, psi_k)");
+        if (P.MNtype == 2 && P.order < 3) return fail(UCF_ERR_MISHRA_NEUMAN, "Mishra/Neuman finite difference order must be >= 3");
+        if (P.MNtype == 0)
+            return fail(UCF_ERR_UNSUPPORTED, "Mishra/Neuman type 0 is the quad-precision ARB path, excluded from this build");
+        if (P.MNtype < 0 || P.MNtype > 2) return fail(UCF_ERR_MISHRA_NEUMAN, "invalid Mishra/Neuman solution type %d", P.MNtype);
+    }
+    if ((P.model == 4 || P.model == 5) && P.beta < 0.0) return fail(UCF_ERR_MALAMA_BETA, "Malama beta cannot be negative");
+    if (P.model == 3)
+        for (int i = 0; i < P.MoenchM; i++)
+            if (P.MoenchAlpha[i] < 0.0) return fail(UCF_ERR_MOENCH, "Moench alphas cannot be negative");
+    if (P.M < 2) return fail(UCF_ERR_DEHOOG, "de Hoog M must be >= 2 (M=%d)", P.M);
+    if (P.M > UCF_MAX_LAP_M) return fail(UCF_ERR_UNSUPPORTED, "de Hoog M=%d: this build maps one Laplace sample per lane (M <= %d)", P.M, UCF_MAX_LAP_M);
+    if (P.k - P.R < 2) return fail(UCF_ERR_TANH_SINH, "tanh-sinh k (%d) too low for %d Richardson levels", P.k, P.R);
+    if (P.R < 1) return fail(UCF_ERR_TANH_SINH, "Richardson extrapolation level must be >= 1");
+    if (P.R > UCF_MAX_R || P.k > 20) return fail(UCF_ERR_UNSUPPORTED, "tanh-sinh k=%d R=%d beyond build limits", P.k, P.R);
+    if (P.j0s[0] < 1 || P.j0s[1] < 1 || P.nacc < 1 || P.k < 1)
+        return fail(UCF_ERR_GAUSS_LOBATTO, "min/max split, # accelerated terms and k must be >= 1");
+    if (P.ord < 3) return fail(UCF_ERR_GAUSS_LOBATTO, "Gauss-Lobatto order must be >= 3");
+    if (P.model == 2) return fail(UCF_ERR_UNSUPPORTED, "model 2 (Hantush with wellbore storage) is not built yet");
+    if (P.timeType < 1 || P.timeType > 8) return fail(UCF_ERR_UNSUPPORTED, "time behaviour %d is not built (1..8 are)", P.timeType);
+    return UCF_OK;
+}
+
+// ---- driver_io.f90:159-186, 531-567
+void nondimensionalise(const ucf_params& P, ucf_derived& D)
+{
+    const double PI = 4.0 * std::atan(1.0);
+    std::memset(&D, 0, sizeof(D));
+    double l = P.l, d = P.d, ac = P.ac;
+    if (P.MNtype == 1) {
+        if (std::fabs(P.ac - P.ak) > FLT_EPSILON) ac = P.ak;
+        if (std::fabs(l - P.b) > FLT_EPSILON) l = P.b;
+        if (d > FLT_EPSILON) d = 0.0;
+    }
+    D.l_eff = l; D.d_eff = d; D.ac_eff = ac;
+    D.Lc = P.b;
+    D.Tc = D.Lc * D.Lc / (P.Kr / P.Ss);
+    D.Hc = P.Q / (4 * PI * P.Kr * P.b);
+    D.sigma = P.Sy / (P.Ss * P.b);
+    D.alphaD = P.kappa / D.sigma;
+    D.betaD = P.beta / D.Lc;
+    D.lD = l / D.Lc;
+    D.dD = d / D.Lc;
+    D.bD = D.lD - D.dD;
+    D.rDw = P.rw / D.Lc;
+    D.rDwobs = P.rwobs / D.Lc;
+    for (int m = 0; m < P.MoenchM && m < UCF_MAX_MOENCH; m++)
+        D.MoenchGamma[m] = P.MoenchAlpha[m] * D.Lc * P.Sy / (P.kappa * P.Kr);
+    D.acD = ac * D.Lc;
+    D.akD = P.ak * D.Lc;
+    D.lambdaD = (P.ak - ac) * D.Lc;
+    D.psiaD = P.psia / D.Lc;
+    D.psikD = P.psik / D.Lc;
+    D.usLD = P.usL / D.Lc;
+    D.b1 = P.psia - P.psik;
+    D.PsiD = D.b1 / D.Lc;
+    D.np = 2 * P.M + 1;
+    D.N = (1 << P.k) - 1;
+    D.nj0z = (P.j0s[0] > P.j0s[1] ? P.j0s[0] : P.j0s[1]) + P.nacc + 1;
+    D.nabs = D.N + P.nacc * (P.ord - 2);
+}
+
+// ---- driver_io.f90:628-647: Newton on J0 from the asymptotic guess (i+3/4)*pi
+void j0_zeros(int n, double* z)
+{
+    const double PI = 4.0 * std::atan(1.0);
+    for (int i = 0; i < n; i++) {
+        double x = (i + 0.75) * PI;
+        for (int it = 0; it < 100; it++) {
+            const double dx = j0(x) / j1(x);
+            x = x + dx;
+            if (std::fabs(dx) < std::nextafter(std::fabs(x), INFINITY) - std::fabs(x)) break;   // spacing(x)
+        }
+        z[i] = x;
+    }
+}
+
+// ---- integration.f90:31-67: weights of a 2^k-1 point rule (sum normalised to 2) and, on
+// request, tanh(u2)+1 (the abscissa on [0,s] is (that)*s/2, applied per point on the device)
+void tanh_sinh_level(int k, double* w, double* x_unit)
+{
+    const double PIOV2 = 2.0 * std::atan(1.0);
+    const int N = (1 << k) - 1, r = (N - 1) / 2;
+    const double h = 4.0 / (double)(1 << k);
+    std::vector<double> u2(N);
+    for (int i = -r; i <= r; i++) {
+        const double u1 = PIOV2 * std::cosh(h * i);
+        u2[i + r] = PIOV2 * std::sinh(h * i);
+        const double c = std::cosh(u2[i + r]);
+        w[i + r] = u1 / (c * c);
+    }
+    double sum = 0.0;
+    for (int i = 0; i < N; i++) sum = sum + w[i];
+    for (int i = 0; i < N; i++) w[i] = 2.0 * w[i] / sum;
+    if (x_unit)
+        for (int i = 0; i < N; i++) x_unit[i] = std::tanh(u2[i]) + 1.0;
+}
+
+// ---- integration.f90:70-120: Newton on the Legendre recurrence; interior nodes only
+void gauss_lobatto(int ord, double* xo, double* wo)
+{
+    const int N = ord - 1, N1 = N + 1;
+    const double PI = 4.0 * std::atan(1.0);
+    std::vector<double> Pm((size_t)ord * ord, 0.0), x(ord), xold(ord, 2.0);
+    auto PP = [&](int i, int k) -> double& { return Pm[(size_t)(k - 1) * ord + i]; };
+    for (int i = 0; i <= N; i++) x[i] = std::cos(PI * i / N);
+    for (int it = 0; it < 1000; it++) {
+        double mx = 0.0;
+        for (int i = 0; i < ord; i++) mx = std::fmax(mx, std::fabs(x[i] - xold[i]));
+        if (!(mx > DBL_EPSILON)) break;
+        for (int i = 0; i < ord; i++) { xold[i] = x[i]; PP(i, 1) = 1.0; PP(i, 2) = x[i]; }
+        for (int k = 2; k <= N; k++)
+            for (int i = 0; i < ord; i++) PP(i, k + 1) = ((2 * k - 1) * x[i] * PP(i, k) - (k - 1) * PP(i, k - 1)) / k;
+        for (int i = 0; i < ord; i++) x[i] = xold[i] - (x[i] * PP(i, N1) - PP(i, N)) / (N1 * PP(i, N1));
+    }
+    for (int i = 1; i <= ord - 2; i++) {
+        xo[i - 1] = x[i];
+        wo[i - 1] = 2.0 / ((N * N1) * (PP(i, N1) * PP(i, N1)));
+    }
+}
+
+int fill_call_params(const ucf_plan* plan, int nz, const double* zD, const int* zLay, ucf_dev_params& dp)
+{
+    if (nz < 1 || nz > UCF_MAX_NZ) return fail(UCF_ERR_BAD_ARGUMENT, "nz=%d out of range 1..%d", nz, UCF_MAX_NZ);
+    if (!zD || !zLay) return fail(UCF_ERR_BAD_ARGUMENT, "zD / zLay must not be NULL");
+    dp = plan->dev;
+    dp.nz = nz;
+    for (int i = 0; i < nz; i++) {
+        if (zLay[i] < 1 || zLay[i] > 3) return fail(UCF_ERR_BAD_ARGUMENT, "zLay[%d]=%d not in 1..3", i, zLay[i]);
+        dp.zD[i] = zD[i];
+        dp.zLay[i] = zLay[i];
+    }
+    return UCF_OK;
+}
+
+struct dev_buf {
+    void* p = nullptr;
+    ~dev_buf() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8) == hipSuccess ? 0 : 1; }
+};
+
+}  // namespace
+
+extern "C" {
+
+int ucf_version(void) { return UCF_VERSION; }
+const char* ucf_last_error(void) { return g_err; }
+
+const char* ucf_status_string(int status)
+{
+    switch (status) {
+    case UCF_OK: return "ok";
+    case UCF_ERR_INVALID_MODEL: return "invalid model";
+    case UCF_ERR_GEOMETRY: return "invalid well geometry";
+    case UCF_ERR_AQUIFER: return "invalid aquifer parameters";
+    case UCF_ERR_MISHRA_NEUMAN: return "invalid Mishra/Neuman parameters";
+    case UCF_ERR_MALAMA_BETA: return "invalid Malama beta";
+    case UCF_ERR_MOENCH: return "invalid Moench parameters";
+    case UCF_ERR_DEHOOG: return "invalid de Hoog parameters";
+    case UCF_ERR_TANH_SINH: return "invalid tanh-sinh parameters";
+    case UCF_ERR_GAUSS_LOBATTO: return "invalid Gauss-Lobatto / split parameters";
+    case UCF_ERR_UNSUPPORTED: return "valid in the reference but not built";
+    case UCF_ERR_BAD_ARGUMENT: return "bad argument";
+    case UCF_ERR_NO_DEVICE: return "no HIP device";
+    case UCF_ERR_HIP: return "HIP runtime error";
+    case UCF_ERR_NOMEM: return "out of memory";
+    case UCF_ERR_OBSERVATION: return "invalid observation well";
+    default: return "unknown status";
+    }
+}
+
+int ucf_plan_create(const ucf_params* Pin, ucf_plan** out)
+{
+    if (!Pin || !out) return fail(UCF_ERR_BAD_ARGUMENT, "NULL argument");
+    *out = nullptr;
+    int rc = validate(*Pin);
+    if (rc) return rc;
+    rc = require_device();
+    if (rc) return rc;
+
+    ucf_plan* pl = new (std::nothrow) ucf_plan();
+    if (!pl) return fail(UCF_ERR_NOMEM, "host allocation failed");
+    std::memset(pl, 0, sizeof(*pl));
+    pl->P = *Pin;
+    if (pl->P.tol < DBL_EPSILON) pl->P.tol = DBL_EPSILON;            // driver_io.f90:311-314
+    const ucf_params& P = pl->P;
+    nondimensionalise(P, pl->D);
+    const ucf_derived& D = pl->D;
+    (void)hipGetDevice(&pl->device);
+
+    const int N = D.N, R = P.R, ngl = P.ord - 2;
+    pl->h_j0z = (double*)std::malloc(sizeof(double) * D.nj0z);
+    pl->h_ts_x = (double*)std::malloc(sizeof(double) * N);
+    pl->h_ts_w = (double*)std::calloc((size_t)R * N, sizeof(double));
+    pl->h_gl_x = (double*)std::malloc(sizeof(double) * ngl);
+    pl->h_gl_w = (double*)std::malloc(sizeof(double) * ngl);
+    j0_zeros(D.nj0z, pl->h_j0z);
+    ucf_dev_params& dp = pl->dev;
+    for (int j = 1; j <= R; j++) {                                    // driver.f90:86-91
+        const int kv = P.k - R + j;
+        pl->Nv[j - 1] = (1 << kv) - 1;
+        dp.hv[j - 1] = 4.0 / (double)(1 << kv);
+        tanh_sinh_level(kv, pl->h_ts_w + (size_t)(j - 1) * N, (j == R) ? pl->h_ts_x : nullptr);
+    }
+    gauss_lobatto(P.ord, pl->h_gl_x, pl->h_gl_w);
+
+    // FD table exp(-beta1*(j-1)*h)  (laplace_hankel_solutions.f90:494)
+    std::vector<double> fd_e;
+    if (P.model == 6 && P.MNtype == 2) {
+        const double h = D.usLD / (double)(P.order - 1);
+        const double beta1 = -D.lambdaD;
+        fd_e.resize(P.order);
+        for (int j = 1; j <= P.order; j++) fd_e[j - 1] = std::exp(-(beta1 * (double)(j - 1) * h));
+        dp.fd_h = h;
+        dp.fd_invhsq = 1.0 / (h * h);
+        dp.fd_beta0 = D.ac_eff * P.Sy / P.Ss;
+        dp.fd_beta3 = D.akD;
+        dp.fd_expmb2 = std::exp(-(P.ak * D.b1));
+    }
+    if (P.model == 6 && P.MNtype == 1) {                              // :420-427
+        const double beta0 = P.ak * P.b;
+        const double phiDa = P.psia / P.b, phiDk = P.psik / P.b;
+        dp.mn_vartheta = beta0 * P.Sy / (P.Ss * P.b) * std::exp(-(beta0 * (phiDa - phiDk)));
+        dp.mn_u0 = beta0 / 2.0;
+    }
+
+    // one device allocation for all tables
+    const size_t n_tab = (size_t)N + (size_t)R * N + 2 * (size_t)ngl + D.nj0z + fd_e.size();
+    std::vector<double> host(n_tab);
+    size_t o = 0;
+    const size_t o_tsx = o; std::memcpy(&host[o], pl->h_ts_x, sizeof(double) * N); o += N;
+    const size_t o_tsw = o; std::memcpy(&host[o], pl->h_ts_w, sizeof(double) * (size_t)R * N); o += (size_t)R * N;
+    const size_t o_glx = o; std::memcpy(&host[o], pl->h_gl_x, sizeof(double) * ngl); o += ngl;
+    const size_t o_glw = o; std::memcpy(&host[o], pl->h_gl_w, sizeof(double) * ngl); o += ngl;
+    const size_t o_j0z = o; std::memcpy(&host[o], pl->h_j0z, sizeof(double) * D.nj0z); o += D.nj0z;
+    const size_t o_fde = o; if (!fd_e.empty()) std::memcpy(&host[o], fd_e.data(), sizeof(double) * fd_e.size());
+    pl->tables_bytes = n_tab * sizeof(double);
+    if (hipMalloc((void**)&pl->d_tables, pl->tables_bytes) != hipSuccess) {
+        ucf_plan_destroy(pl);
+        return fail(UCF_ERR_NOMEM, "hipMalloc of %zu table bytes failed", pl->tables_bytes);
+    }
+    if (hipMemcpy(pl->d_tables, host.data(), pl->tables_bytes, hipMemcpyHostToDevice) != hipSuccess) {
+        ucf_plan_destroy(pl);
+        return fail(UCF_ERR_HIP, "table upload failed");
+    }
+
+    dp.model = P.model; dp.MNtype = P.MNtype; dp.order = P.order; dp.timeType = P.timeType; dp.MoenchM = P.MoenchM;
+    dp.M = P.M; dp.np = D.np; dp.k = P.k; dp.N = N; dp.R = R; dp.nacc = P.nacc; dp.ngl = ngl; dp.nz = 0;
+    dp.nj0z = D.nj0z;
+    dp.timePar[0] = P.timePar[0]; dp.timePar[1] = P.timePar[1];
+    dp.kappa = P.kappa; dp.alphaD = D.alphaD; dp.beta = P.beta;
+    dp.lD = D.lD; dp.dD = D.dD; dp.bD = D.bD; dp.dD1 = 1.0 - D.dD; dp.lD1 = 1.0 - D.lD;
+    for (int m = 0; m < P.MoenchM; m++) dp.MoenchInvGamma[m] = 1.0 / D.MoenchGamma[m];
+    dp.alpha = P.alpha; dp.logtol = std::log(P.tol); dp.maxexp = -std::log(DBL_EPSILON) / 3.0;   // constants.f90:66
+    dp.ts_x = pl->d_tables + o_tsx;
+    dp.ts_w = pl->d_tables + o_tsw;
+    dp.gl_x = pl->d_tables + o_glx;
+    dp.gl_w = pl->d_tables + o_glw;
+    dp.j0z = pl->d_tables + o_j0z;
+    dp.fd_e = pl->d_tables + o_fde;
+    pl->mode = 0;
+    *out = pl;
+    return UCF_OK;
+}
+
+void ucf_plan_destroy(ucf_plan* pl)
+{
+    if (!pl) return;
+    if (pl->d_tables) (void)hipFree(pl->d_tables);
+    std::free(pl->h_j0z); std::free(pl->h_ts_x); std::free(pl->h_ts_w); std::free(pl->h_gl_x); std::free(pl->h_gl_w);
+    delete pl;
+}
+
+int ucf_plan_derived(const ucf_plan* pl, ucf_derived* out)
+{
+    if (!pl || !out) return fail(UCF_ERR_BAD_ARGUMENT, "NULL argument");
+    *out = pl->D;
+    return UCF_OK;
+}
+
+int ucf_plan_j0z(const ucf_plan* pl, int n, double* j0z)
+{
+    if (!pl || !j0z || n > pl->D.nj0z) return fail(UCF_ERR_BAD_ARGUMENT, "bad j0z request");
+    std::memcpy(j0z, pl->h_j0z, sizeof(double) * n);
+    return UCF_OK;
+}
+
+int ucf_plan_tanh_sinh(const ucf_plan* pl, int level, int n, double* w, double* x_unit)
+{
+    if (!pl || !w || level < 1 || level > pl->P.R) return fail(UCF_ERR_BAD_ARGUMENT, "bad tanh-sinh level");
+    if (n != pl->Nv[level - 1]) return fail(UCF_ERR_BAD_ARGUMENT, "level %d has %d abscissae", level, pl->Nv[level - 1]);
+    std::memcpy(w, pl->h_ts_w + (size_t)(level - 1) * pl->D.N, sizeof(double) * n);
+    if (x_unit) {
+        if (level != pl->P.R) return fail(UCF_ERR_BAD_ARGUMENT, "abscissae exist for the densest level only");
+        std::memcpy(x_unit, pl->h_ts_x, sizeof(double) * n);
+    }
+    return UCF_OK;
+}
+
+int ucf_plan_gauss_lobatto(const ucf_plan* pl, int n, double* x, double* w)
+{
+    if (!pl || !x || !w || n != pl->P.ord - 2) return fail(UCF_ERR_BAD_ARGUMENT, "bad Gauss-Lobatto request");
+    std::memcpy(x, pl->h_gl_x, sizeof(double) * n);
+    std::memcpy(w, pl->h_gl_w, sizeof(double) * n);
+    return UCF_OK;
+}
+
+int ucf_plan_set_mode(ucf_plan* pl, int mode)
+{
+    if (!pl || (mode != 0 && mode != 1)) return fail(UCF_ERR_BAD_ARGUMENT, "mode must be 0 (faithful) or 1 (fast)");
+    pl->mode = mode;
+    return UCF_OK;
+}
+
+// ---- utility.f90:34-57
+int ucf_linspace(double lo, double hi, int n, double* v)
+{
+    if (n < 1 || !v) return fail(UCF_ERR_BAD_ARGUMENT, "bad linspace request");
+    if (n == 1) {
+        v[0] = (lo + hi) / 2.0;
+    } else {
+        const double dx = (hi - lo) / (n - 1);
+        for (int i = 1; i <= n; i++) v[i - 1] = lo + (i - 1) * dx;
+    }
+    return UCF_OK;
+}
+int ucf_logspace(int lo, int hi, int n, double* v)
+{
+    int rc = ucf_linspace((double)lo, (double)hi, n, v);
+    if (rc) return rc;
+    for (int i = 0; i < n; i++) v[i] = std::pow(10.0, v[i]);
+    return UCF_OK;
+}
+
+// ---- driver_io.f90:575-586
+int ucf_zlay(const ucf_plan* pl, int nz, const double* zD, int* zLay)
+{
+    if (!pl || !zD || !zLay) return fail(UCF_ERR_BAD_ARGUMENT, "NULL argument");
+    for (int i = 0; i < nz; i++) {
+        if (zD[i] <= 0.0 || zD[i] < (1.0 - pl->D.lD)) zLay[i] = 1;
+        else if ((zD[i] - 1.0) >= 0.0 || zD[i] < (1.0 - pl->D.dD)) zLay[i] = 2;
+        else zLay[i] = 3;
+    }
+    return UCF_OK;
+}
+
+// ---- driver_io.f90:654-664
+int ucf_split_vector(const ucf_plan* pl, int nt, const double* tD, int* sv)
+{
+    if (!pl || !tD || !sv || nt < 1) return fail(UCF_ERR_BAD_ARGUMENT, "bad split-vector request");
+    const int* j0s = pl->P.j0s;
+    const int mx = j0s[0] > j0s[1] ? j0s[0] : j0s[1], mn = j0s[0] < j0s[1] ? j0s[0] : j0s[1];
+    const int zrange = mx - mn;
+    double lmin = INFINITY, lmax = -INFINITY;
+    for (int i = 0; i < nt; i++) {
+        const double lg = std::log10(tD[i]);
+        lmin = std::fmin(lmin, lg);
+        lmax = std::fmax(lmax, lg);
+    }
+    const int minlsp = (int)std::floor(lmin), maxlsp = (int)std::ceil(lmax);
+    const int sprange = maxlsp - minlsp + 1;
+    for (int i = 0; i < nt; i++) sv[i] = mn + (int)(zrange * ((maxlsp - std::log10(tD[i])) / sprange));
+    return UCF_OK;
+}
+
+// ---- driver.f90:234-243
+int ucf_screen_average(int npts, int zOrd, const double* h, double* havg)
+{
+    if (!h || !havg || zOrd < 1) return fail(UCF_ERR_BAD_ARGUMENT, "bad screen-average request");
+    for (int i = 0; i < npts; i++) {
+        const double* v = h + (size_t)i * zOrd;
+        if (zOrd == 1) { havg[i] = v[0]; continue; }
+        double s = v[1];
+        for (int j = 2; j < zOrd; j++) s = s + v[j];
+        havg[i] = ((v[0] + 2.0 * s) + v[zOrd - 1]) / (2 * zOrd);
+    }
+    return UCF_OK;
+}
+
+// ---- the hot path
+int ucf_drawdown_batch_device(ucf_plan* pl, int npts, const double* d_tD, const double* d_rD, const int* d_sv,
+                              int nz, const double* zD, const int* zLay, double* d_h, double* d_dh,
+                              ucf_stats* d_stats, void* stream)
+{
+    if (!pl) return fail(UCF_ERR_BAD_ARGUMENT, "NULL plan");
+    if (npts < 0) return fail(UCF_ERR_BAD_ARGUMENT, "npts < 0");
+    if (npts == 0) return UCF_OK;
+    if (!d_tD || !d_rD || !d_sv || !d_h || !d_dh) return fail(UCF_ERR_BAD_ARGUMENT, "NULL device array");
+    ucf_dev_params dp;
+    int rc = fill_call_params(pl, nz, zD, zLay, dp);
+    if (rc) return rc;
+    rc = (pl->mode == 1) ? ucf_fast::launch_points(dp, npts, d_tD, d_rD, d_sv, d_h, d_dh, d_stats, stream)
+                         : ucf_faithful::launch_points(dp, npts, d_tD, d_rD, d_sv, d_h, d_dh, d_stats, stream);
+    if (rc == UCF_ERR_UNSUPPORTED) return fail(rc, "this model / size combination has no kernel (model %d, LDS limit)", dp.model);
+    if (rc) return fail(rc, "kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+    return UCF_OK;
+}
+
+int ucf_drawdown_batch(ucf_plan* pl, int npts, const double* tD, const double* rD, const int* sv,
+                       int nz, const double* zD, const int* zLay, double* h, double* dh, ucf_stats* stats)
+{
+    if (!pl) return fail(UCF_ERR_BAD_ARGUMENT, "NULL plan");
+    if (npts < 0) return fail(UCF_ERR_BAD_ARGUMENT, "npts < 0");
+    if (stats) std::memset(stats, 0, sizeof(*stats));
+    if (npts == 0) return UCF_OK;
+    if (!tD || !rD || !sv || !h || !dh) return fail(UCF_ERR_BAD_ARGUMENT, "NULL array");
+    for (int i = 0; i < npts; i++)
+        if (sv[i] < 1 || sv[i] + pl->P.nacc > pl->D.nj0z)
+            return fail(UCF_ERR_BAD_ARGUMENT, "sv[%d]=%d outside 1..%d", i, sv[i], pl->D.nj0z - pl->P.nacc);
+    dev_buf b_t, b_r, b_s, b_h, b_d, b_st;
+    const size_t nb = sizeof(double) * (size_t)npts;
+    if (b_t.alloc(nb) || b_r.alloc(nb) || b_s.alloc(sizeof(int) * (size_t)npts) || b_h.alloc(nb * nz) ||
+        b_d.alloc(nb * nz) || b_st.alloc(sizeof(ucf_stats)))
+        return fail(UCF_ERR_NOMEM, "device allocation failed for %d points", npts);
+    HIP_TRY(hipMemcpy(b_t.p, tD, nb, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(b_r.p, rD, nb, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(b_s.p, sv, sizeof(int) * (size_t)npts, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(b_st.p, 0, sizeof(ucf_stats)));
+    int rc = ucf_drawdown_batch_device(pl, npts, (const double*)b_t.p, (const double*)b_r.p, (const int*)b_s.p, nz, zD,
+                                       zLay, (double*)b_h.p, (double*)b_d.p, stats ? (ucf_stats*)b_st.p : nullptr, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(h, b_h.p, nb * nz, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(dh, b_d.p, nb * nz, hipMemcpyDeviceToHost));
+    if (stats) HIP_TRY(hipMemcpy(stats, b_st.p, sizeof(ucf_stats), hipMemcpyDeviceToHost));
+    return UCF_OK;
+}
+
+// ---- stage hooks
+int ucf_eval_samples(ucf_plan* pl, int n_a, const double* a, double rD, int np, const double* p_re_im,
+                     int nz, const double* zD, const int* zLay, double* fp_re_im)
+{
+    if (!pl || !a || !p_re_im || !fp_re_im || n_a < 1) return fail(UCF_ERR_BAD_ARGUMENT, "bad sample request");
+    if (np != pl->D.np) return fail(UCF_ERR_BAD_ARGUMENT, "np=%d but the plan has 2M+1=%d", np, pl->D.np);
+    ucf_dev_params dp;
+    int rc = fill_call_params(pl, nz, zD, zLay, dp);
+    if (rc) return rc;
+    dev_buf b_a, b_p, b_f;
+    const size_t nf = sizeof(double) * 2 * (size_t)n_a * nz * np;
+    if (b_a.alloc(sizeof(double) * n_a) || b_p.alloc(sizeof(double) * 2 * np) || b_f.alloc(nf))
+        return fail(UCF_ERR_NOMEM, "device allocation failed");
+    HIP_TRY(hipMemcpy(b_a.p, a, sizeof(double) * n_a, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(b_p.p, p_re_im, sizeof(double) * 2 * np, hipMemcpyHostToDevice));
+    rc = (pl->mode == 1) ? ucf_fast::launch_samples(dp, n_a, (const double*)b_a.p, rD, (const double*)b_p.p, (double*)b_f.p, nullptr)
+                         : ucf_faithful::launch_samples(dp, n_a, (const double*)b_a.p, rD, (const double*)b_p.p, (double*)b_f.p, nullptr);
+    if (rc) return fail(rc, "sample kernel launch failed");
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(fp_re_im, b_f.p, nf, hipMemcpyDeviceToHost));
+    return UCF_OK;
+}
+
+int ucf_pvalues(const ucf_plan* pl, double tee, double* p_re_im)
+{
+    if (!pl || !p_re_im) return fail(UCF_ERR_BAD_ARGUMENT, "NULL argument");
+    const double PI = 4.0 * std::atan(1.0);
+    const double sigma = pl->P.alpha - std::log(pl->P.tol) / (2.0 * tee);      // invlap.f90:165
+    for (int i = 0; i <= 2 * pl->P.M; i++) {
+        p_re_im[2 * i] = sigma;
+        p_re_im[2 * i + 1] = PI * i / tee;                                     // :168
+    }
+    return UCF_OK;
+}
+
+int ucf_dehoog(int n, int M, double alpha, double tol, const double* t, const double* tee, const double* fp, double* ft)
+{
+    if (n < 1 || !t || !tee || !fp || !ft) return fail(UCF_ERR_BAD_ARGUMENT, "bad de Hoog request");
+    if (M < 1 || M > UCF_MAX_LAP_M) return fail(UCF_ERR_UNSUPPORTED, "M=%d outside 1..%d", M, UCF_MAX_LAP_M);
+    int rc = require_device();
+    if (rc) return rc;
+    dev_buf b_t, b_e, b_f, b_o;
+    const int np = 2 * M + 1;
+    if (b_t.alloc(sizeof(double) * n) || b_e.alloc(sizeof(double) * n) || b_f.alloc(sizeof(double) * 2 * (size_t)n * np) ||
+        b_o.alloc(sizeof(double) * n))
+        return fail(UCF_ERR_NOMEM, "device allocation failed");
+    HIP_TRY(hipMemcpy(b_t.p, t, sizeof(double) * n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(b_e.p, tee, sizeof(double) * n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(b_f.p, fp, sizeof(double) * 2 * (size_t)n * np, hipMemcpyHostToDevice));
+    rc = ucf_faithful::launch_dehoog(n, M, alpha, std::log(tol), (const double*)b_t.p, (const double*)b_e.p,
+                                     (const double*)b_f.p, (double*)b_o.p, nullptr);
+    if (rc) return fail(rc, "de Hoog kernel launch failed");
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(ft, b_o.p, sizeof(double) * n, hipMemcpyDeviceToHost));
+    return UCF_OK;
+}
+
+int ucf_wynn_epsilon(int n, int nterms, const double* series, double* acc, int* status)
+{
+    if (n < 1 || nterms < 1 || nterms > 64 || !series || !acc || !status) return fail(UCF_ERR_BAD_ARGUMENT, "bad Wynn request");
+    int rc = require_device();
+    if (rc) return rc;
+    dev_buf b_s, b_a, b_st;
+    if (b_s.alloc(sizeof(double) * 2 * (size_t)n * nterms) || b_a.alloc(sizeof(double) * 2 * n) || b_st.alloc(sizeof(int) * n))
+        return fail(UCF_ERR_NOMEM, "device allocation failed");
+    HIP_TRY(hipMemcpy(b_s.p, series, sizeof(double) * 2 * (size_t)n * nterms, hipMemcpyHostToDevice));
+    rc = ucf_faithful::launch_wynn(n, nterms, (const double*)b_s.p, (double*)b_a.p, (int*)b_st.p, nullptr);
+    if (rc) return fail(rc, "Wynn kernel launch failed");
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(acc, b_a.p, sizeof(double) * 2 * n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(status, b_st.p, sizeof(int) * n, hipMemcpyDeviceToHost));
+    return UCF_OK;
+}
+
+int ucf_extraptozero(int n, int R, const double* x, const double* y, double* out)
+{
+    if (n < 1 || R < 1 || R > UCF_MAX_R || !x || !y || !out) return fail(UCF_ERR_BAD_ARGUMENT, "bad extrapolation request");
+    int rc = require_device();
+    if (rc) return rc;
+    dev_buf b_x, b_y, b_o;
+    if (b_x.alloc(sizeof(double) * R) || b_y.alloc(sizeof(double) * 2 * (size_t)n * R) || b_o.alloc(sizeof(double) * 2 * n))
+        return fail(UCF_ERR_NOMEM, "device allocation failed");
+    HIP_TRY(hipMemcpy(b_x.p, x, sizeof(double) * R, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(b_y.p, y, sizeof(double) * 2 * (size_t)n * R, hipMemcpyHostToDevice));
+    rc = ucf_faithful::launch_extrap(n, R, (const double*)b_x.p, (const double*)b_y.p, (double*)b_o.p, nullptr);
+    if (rc) return fail(rc, "extrapolation kernel launch failed");
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, b_o.p, sizeof(double) * 2 * n, hipMemcpyDeviceToHost));
+    return UCF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,661 @@
+// ucf_device.h -- the hot path on the device.  Included twice by ucf_kernels.hip
+// (UCF_FAST = 0 -> namespace ucf_faithful, UCF_FAST = 1 -> namespace ucf_fast).
+//
+// Mapping: one 64-lane wavefront owns one (t,r)
+// point; lane m owns Laplace sample p_m (2M+1 <= 64 of them); the wave walks the
+// Hankel abscissae serially, so the quadrature sums keep the reference's
+// summation order and need no cross-lane traffic.  Level sums / interval areas
+// live in LDS ([slot][lane] complex, 16 B per lane -> conflict-free b128
+// accesses); Richardson/Neville and Wynn-epsilon run per lane on those LDS
+// columns; only de Hoog's quotient-difference table needs neighbours (lane i+1),
+// which is a wave shuffle.  Nothing but 20 B in and 16*nz B out per point
+// touches HBM; the quadrature tables (< 10 KB) are read through the scalar cache.
+//
+// Every device function cites the reference lines it restates.
+
+#include "ucf_math.h"
+#include "ucf_plan.h"
+
+namespace UCF_NS {
+
+using namespace ucfm;
+
+#define UCF_PI 3.14159265358979323846   /* 4*atan(1) in binary64 */
+#define UCF_EPS 2.220446049250313e-16
+
+// ------------------------------------------------------------------ wave helpers
+UCF_DEV double shfl_down1(double v) { return __shfl_down(v, 1, 64); }
+UCF_DEV cplx shfl_down1(cplx v) { return cmake(__shfl_down(v.re, 1, 64), __shfl_down(v.im, 1, 64)); }
+UCF_DEV cplx bcast0(cplx v) { return cmake(__shfl(v.re, 0, 64), __shfl(v.im, 0, 64)); }
+UCF_DEV double wave_max(double v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+    return v;
+}
+UCF_DEV void stat_add(long long* ctr, bool pred)
+{
+    if (ctr == nullptr) return;
+    unsigned long long bal = __ballot(pred);
+    if (bal != 0ull && (threadIdx.x & 63) == 0) atomicAdd((unsigned long long*)ctr, (unsigned long long)__popcll(bal));
+}
+
+typedef double2 lds_c;   // one complex per lane per slot
+UCF_DEV cplx lds_ld(const lds_c* base, int slot, int lane) { lds_c v = base[slot * UCF_WAVE + lane]; return cmake(v.x, v.y); }
+UCF_DEV void lds_st(lds_c* base, int slot, int lane, cplx z) { base[slot * UCF_WAVE + lane] = make_double2(z.re, z.im); }
+
+// ------------------------------------------------------------------ time.f90:34-80
+UCF_DEV cplx lap_time(const ucf_dev_params& P, cplx p)
+{
+    const double t1 = P.timePar[0], t2 = P.timePar[1];
+    switch (P.timeType) {
+    case 1: return cdiv(cexp_(cscale(p, -t1)), p);                                               // :47-49
+    case 2: return csub(cdiv(cexp_(cscale(p, -t1)), p), cdiv(cexp_(cscale(p, -t2)), p));         // :50-52
+    case 3: return cexp_(cscale(p, -t1));                                                        // :53-55
+    case 4: {                                                                                    // :56-60
+        cplx a = rdiv(1.0, csub(p, cmul(p, cexp_(cscale(p, -t1)))));
+        cplx b = rsub(1.0, cexp_(cscale(p, -t2)));
+        return cdiv(cmul(a, b), p);
+    }
+    case 5: return cdiv(cexp_(cscale(p, -t2)), cadd(p, cmul(p, cexp_(cscale(p, -t1)))));         // :61-64
+    case 6: return cdiv(cmul(cexp_(cscale(p, -t2)), p), caddr(cmul(p, p), t1 * t1));             // :65-68
+    case 7: return cmake(0.0, 0.0);                                                              // :69-74 (quirk Q4)
+    case 8: {                                                                                    // :75-80
+        cplx ex = cexp_(cdivr(cscale(p, -t1), 2.0));
+        cplx num = cmul(cexp_(cscale(p, -t2)), rsub(1.0, ex));
+        return cdiv(num, cmul(radd(1.0, ex), p));
+    }
+    default: return cmake(__builtin_nan(""), __builtin_nan(""));
+    }
+}
+
+// ------------------------------------------- laplace_hankel_solutions.f90:30-120
+// z-independent part of one (a,p) sample
+struct sample_common {
+    cplx th;        // theis: 2/(p+a^2)                                   (:122-131)
+    cplx eta;       // sqrt((p+a^2)/kappa)                                (:69,172)
+    cplx ff1, ff2;  // sinh(eta*dD), sinh(eta*lD1)                        (:176-177)
+    cplx she, che;  // sinh(eta), cosh(eta)
+    cplx g3;        // below-screen factor                                (:183-184)
+    cplx top;       // Hantush value at the water table zD=1 (layer 3)    (:81,162-170)
+    cplx den;       // water-table closure denominator                    (:86-87 or :90-91)
+    cplx mn_pre, mn_uod;   // Mishra/Neuman-Malama: 2/(kappa*etasq), u/Delta0  (:437-439)
+    cplx fd_s1;     // Mishra/Neuman FD: sigma(1) = A1                     (:517-523)
+    bool small_eta; // Re(eta) < MAXEXP                                   (:84)
+    bool fd_use;    // |sigma1| > tiny                                    (:521)
+};
+
+// laplace_hankel_solutions.f90:133-202 for one depth; `lay` = layer of this depth
+UCF_DEV cplx hantush_z(const ucf_dev_params& P, const sample_common& S, double zD, int lay, cplx chz)
+{
+    cplx udp;
+    if (lay == 1) {
+        udp = cmul(S.g3, chz);                                                                  // :188
+    } else {
+        cplx ch1z = ccosh_(cscale(S.eta, 1.0 - zD));
+        cplx g2 = cdiv(cadd(cmul(S.ff1, chz), cmul(S.ff2, ch1z)), S.she);                       // :179-180
+        if (lay == 2) {
+            udp = rsub(1.0, g2);                                                                // :192
+        } else {
+            cplx g1 = ccosh_(cscale(S.eta, P.dD1 - zD));                                        // :175
+            udp = csub(g1, g2);                                                                 // :196
+        }
+    }
+    return cdivr(cmul(udp, S.th), P.bD);                                                        // :200
+}
+
+template <int FAMILY>   // 0 Theis, 1 Hantush, 2 water-table (models 3,4,5), 3 MN-Malama, 4 MN-FD
+UCF_DEV void sample_prepare(const ucf_dev_params& P, double a, cplx p, bool need_lay1, sample_common& S,
+                            lds_c* fdbuf, int lane)
+{
+    const double a2 = a * a;
+    const cplx q = caddr(p, a2);
+    S.th = rdiv(2.0, q);
+    if (FAMILY == 0) return;
+    if (FAMILY == 3) {                                                                          // :404-442
+        cplx eta1 = csqrt_(cdivr(caddr(cscale(p, P.mn_vartheta), a2), P.kappa));
+        cplx e1 = cdivr(eta1, P.mn_u0);
+        cplx v = csqrt_(radd(1.0, cmul(e1, e1)));
+        cplx u = rscale(P.mn_u0, rsub(1.0, v));
+        cplx etasq = cdivr(q, P.kappa);
+        S.eta = csqrt_(etasq);
+        cplx Delta0 = csub(cmul(S.eta, csinh_(S.eta)), cmul(u, ccosh_(S.eta)));
+        S.mn_pre = rdiv(2.0, rscale(P.kappa, etasq));
+        S.mn_uod = cdiv(u, Delta0);
+        return;
+    }
+    S.eta = csqrt_(cdivr(q, P.kappa));
+    const bool hantush_needed = !(FAMILY == 2 && P.model == 4);
+    if (hantush_needed) {
+        S.ff1 = csinh_(cscale(S.eta, P.dD));
+        S.ff2 = csinh_(cscale(S.eta, P.lD1));
+        S.she = csinh_(S.eta);
+        if (need_lay1)
+            S.g3 = csub(cexp_(cneg(cscale(S.eta, P.lD1))),
+                        cdiv(cadd(S.ff1, cmul(cexp_(cneg(S.eta)), S.ff2)), S.she));             // :183-184
+    }
+    if (FAMILY == 1) return;
+    S.che = ccosh_(S.eta);
+    // water-table value of the confined solution: theis (model 4) or hantush at zD = 1, layer 3
+    if (FAMILY == 2 && P.model == 4) {
+        S.top = S.th;                                                                           // :78-79
+    } else {
+        // cosh(eta*1) == cosh(eta);  cosh(eta*(1-1)) = cosh((+0, +-0)) = (1, (+0)*(+-0))
+        const cplx ch0 = cmake(1.0, 0.0 * (S.eta.im * 0.0));
+        cplx g2 = cdiv(cadd(cmul(S.ff1, S.che), cmul(S.ff2, ch0)), S.she);
+        cplx g1 = ccosh_(cscale(S.eta, P.dD1 - 1.0));
+        S.top = cdivr(cmul(csub(g1, g2), S.th), P.bD);
+    }
+    if (FAMILY == 2) {
+        cplx xi = cdiv(cscale(S.eta, P.alphaD), p);                                             // :70
+        if (P.model == 3) {                                                                     // :72-75
+            cplx sum = cmake(0.0, 0.0);
+            for (int j = 0; j < P.MoenchM; j++) {
+                cplx t = rdiv(1.0, radd(1.0, cscale(p, P.MoenchInvGamma[j])));
+                sum = (j == 0) ? t : cadd(sum, t);
+            }
+            xi = cdiv(cscale(xi, (double)P.MoenchM), sum);
+        }
+        S.small_eta = S.eta.re < P.maxexp;                                                      // :84
+        cplx one_bex = radd(1.0, cmul(rscale(P.beta, S.eta), xi));
+        if (S.small_eta) {
+            S.she = hantush_needed ? S.she : csinh_(S.eta);
+            S.den = cadd(cmul(one_bex, S.che), cmul(xi, S.she));                                // :86-87
+        } else {
+            S.den = cadd(one_bex, xi);                                                          // :90-91
+        }
+        return;
+    }
+    if (FAMILY == 4) {                                                                          // :444-544
+        // FD system in the vadose zone; complex Thomas (utility.f90:96-135) per lane.
+        // bp/vp of the forward sweep are kept in this lane's LDS column fdbuf[2*order].
+        const int n = P.order;
+        const double h = P.fd_h, invhsq = P.fd_invhsq, b3h = P.fd_beta3 / h;
+        const cplx B1 = cdivr(cscale(cscale(p, P.fd_beta0), P.fd_expmb2), P.kappa);            // :492
+        const double B2 = a2 / P.kappa;                                                         // :493
+        const cplx om1 = caddr(cscale(B1, P.fd_e[0]), B2);                                      // :495
+        const cplx cc = rsub(b3h - invhsq, om1);                                                // :498
+        const cplx eoh = cdivr(S.eta, h);
+        const cplx b1 = rscale(0.5, cadd(cmul(cexp_(S.eta), csub(cc, eoh)),
+                                         cmul(cexp_(cneg(S.eta)), cadd(cc, eoh))));             // :499-500
+        const double csup = invhsq - b3h;                                                       // :505
+        const cplx a2v = cmul(cmake(invhsq, 0.0), S.che);                                       // :508-509
+        const cplx v1 = cmul(cneg(cc), S.top);                                                  // :514
+        const cplx v2 = rscale(-invhsq, S.top);                                                 // :513
+        // forward sweep
+        cplx bp = b1, vp = v1;
+        lds_st(fdbuf, 0, lane, bp);
+        lds_st(fdbuf, n, lane, vp);
+        for (int i = 2; i <= n; i++) {
+            cplx bi = rsub(b3h - 2.0 * invhsq, caddr(cscale(B1, P.fd_e[i - 1]), B2));           // :501
+            if (i == n) bi = csubr(caddr(bi, invhsq), b3h);                                     // :502
+            cplx ai = (i == 2) ? a2v : cmake(invhsq, 0.0);
+            cplx vi = (i == 2) ? v2 : cmake(0.0, 0.0);
+            cplx mm = cdiv(ai, bp);
+            bp = csub(bi, cmul(mm, cmake(csup, 0.0)));
+            vp = csub(vi, cmul(mm, vp));
+            lds_st(fdbuf, i - 1, lane, bp);
+            lds_st(fdbuf, n + i - 1, lane, vp);
+        }
+        // back substitution down to x(1)
+        cplx x = cdiv(vp, bp);
+        for (int i = n - 1; i >= 1; i--) {
+            cplx bpi = lds_ld(fdbuf, i - 1, lane);
+            cplx vpi = lds_ld(fdbuf, n + i - 1, lane);
+            x = cdiv(csub(vpi, cmul(cmake(csup, 0.0), x)), bpi);
+        }
+        S.fd_s1 = x;
+        S.fd_use = cabs_(x) > UCF_DBL_MIN;                                                      // :521
+    }
+}
+
+template <int FAMILY>
+UCF_DEV cplx sample_z(const ucf_dev_params& P, const sample_common& S, int iz)
+{
+    if (FAMILY == 0) return S.th;
+    const double zD = P.zD[iz];
+    const int lay = P.zLay[iz];
+    if (FAMILY == 3) {
+        return cmul(S.mn_pre, radd(1.0, cmul(S.mn_uod, ccosh_(cscale(S.eta, zD)))));            // :437-439
+    }
+    const cplx chz = ccosh_(cscale(S.eta, zD));
+    if (FAMILY == 1) return hantush_z(P, S, zD, lay, chz);
+    if (FAMILY == 2) {
+        const cplx u = (P.model == 4) ? S.th : hantush_z(P, S, zD, lay, chz);
+        if (S.small_eta) return csub(u, cdiv(cmul(S.top, chz), S.den));                         // :85-87
+        return csub(u, cdiv(cmul(S.top, cexp_(cscale(S.eta, zD - 1.0))), S.den));               // :89-91
+    }
+    // FAMILY 4
+    const cplx sH = hantush_z(P, S, zD, lay, chz);
+    if (S.fd_use) return cadd(sH, cmul(S.fd_s1, chz));                                          // :522-523
+    return sH;                                                                                  // :525
+}
+
+// ------------------------------------------------------------------ invlap.f90:46-141
+// Wave-cooperative de Hoog: lane i holds f(p_i), i = 0..2M.  Returns f(t) (uniform).
+UCF_DEV double dehoog_wave(cplx f, int M, double alpha, double logtol, double t, double tee, int lane,
+                           ucf_stats* st)
+{
+    const int n2 = 2 * M;
+    const bool act = lane <= n2;
+    double mag = act ? cabs_(f) : 0.0;
+    if (d_isnan(mag)) mag = 0.0;                         // MAXVAL skips NaN operands
+    const double mx = wave_max(mag);
+    if (!(mx > UCF_DBL_MIN)) {                           // :69,139
+        if (st) stat_add(&st->zero_vectors, lane == 0);
+        return 0.0;
+    }
+    const bool nanp = act && (d_isnan(f.re) || d_isnan(f.im));
+    if (st) stat_add(&st->nan_scrubbed, nanp);
+    cplx ff = (nanp || !act) ? cmake(act ? 0.0 : 1.0, 0.0) : f;                                 // :71-74
+    const double gamma = alpha - logtol / (2.0 * tee);                                          // :77
+
+    const cplx ff0 = bcast0(ff);
+    const cplx d0 = cdivr(ff0, 2.0);                                                            // :98
+    cplx fnext = shfl_down1(ff);
+    cplx q = (lane == 0) ? cdiv(fnext, d0) : cdiv(fnext, ff);                                   // :81-82  q(i,1)
+    if (lane > n2 - 1) q = cmake(1.0, 0.0);
+    cplx e = cmake(0.0, 0.0);                                                                   // :80     e(i,0)
+
+    cplx Am2 = cmake(0.0, 0.0), Am1 = d0, Bm2 = cmake(1.0, 0.0), Bm1 = cmake(1.0, 0.0);         // :105-107
+    const cplx z = cexp_(cdivr(cscale(cscale(cmake(0.0, 1.0), UCF_PI), t), tee));               // :110
+    cplx dlast_q = cmake(0.0, 0.0), dlast_e = cmake(0.0, 0.0);
+    for (int r = 1; r <= M; r++) {                                                              // :85-95
+        const cplx qn = shfl_down1(q);
+        const cplx en = shfl_down1(e);
+        cplx enew = cadd(csub(qn, q), en);
+        if (lane > 2 * (M - r)) enew = cmake(1.0, 0.0);      // outside the rhombus: keep lanes benign
+        const cplx dq = cneg(bcast0(q));                     // d(2r-1) = -q(0,r)                :100
+        const cplx de = cneg(bcast0(enew));                  // d(2r)   = -e(0,r)                :101
+        {                                                    // n = 2r-1                         :114-117
+            cplx An = cadd(Am1, cmul(cmul(dq, Am2), z));
+            cplx Bn = cadd(Bm1, cmul(cmul(dq, Bm2), z));
+            Am2 = Am1; Am1 = An; Bm2 = Bm1; Bm1 = Bn;
+        }
+        if (r < M) {
+            cplx An = cadd(Am1, cmul(cmul(de, Am2), z));     // n = 2r
+            cplx Bn = cadd(Bm1, cmul(cmul(de, Bm2), z));
+            Am2 = Am1; Am1 = An; Bm2 = Bm1; Bm1 = Bn;
+            const cplx enn = shfl_down1(enew);
+            q = cdiv(cmul(qn, enn), enew);                                                      // :93
+            if (lane > 2 * (M - r - 1) + 1) q = cmake(1.0, 0.0);
+            e = enew;
+        } else {
+            dlast_q = dq;
+            dlast_e = de;
+        }
+    }
+    // :120-125 improved remainder
+    const cplx brem = cdivr(radd(1.0, cmul(csub(dlast_q, dlast_e), z)), 2.0);
+    const cplx inner = csqrt_(radd(1.0, cdiv(cmul(dlast_e, z), cmul(brem, brem))));
+    const cplx rem = cneg(cmul(brem, rsub(1.0, inner)));
+    const cplx A2M = cadd(Am1, cmul(rem, Am2));
+    const cplx B2M = cadd(Bm1, cmul(rem, Bm2));
+    return exp(gamma * t) / tee * cdiv(A2M, B2M).re;                                            // :129
+}
+
+// ------------------------------------------------------------- integration.f90:125-189
+// Per-lane Wynn-epsilon on LDS columns.  colA[(i*strideA)][lane] holds series(i+1) on
+// entry (overwritten by the even epsilon columns); colB is scratch (odd columns).
+// status: 0 ok, 1 truncated, 2 sentinel, 3 early exit.
+UCF_DEV cplx wynn_lane(lds_c* colA, int strideA, lds_c* colB, int nin, int lane, int* status)
+{
+    int ns = nin;
+    int stat = 0;
+    cplx run = cmake(0.0, 0.0);
+    for (int i = 1; i <= nin; i++) {                                                            // :140-163
+        cplx s = lds_ld(colA, (i - 1) * strideA, lane);
+        if (!c_is_finite(s)) {
+            ns = i - 1;
+            stat = (ns < 4) ? 2 : 1;
+            break;
+        }
+        run = (i == 1) ? s : cadd(run, s);
+        lds_st(colA, (i - 1) * strideA, lane, run);
+    }
+    if (stat == 2) {
+        *status = 2;
+        return cmake((double)(-999999.9f), 0.0);                                                // :148
+    }
+    for (int m = 0; m < ns; m++) lds_st(colB, m, lane, cmake(0.0, 0.0));                        // :166
+    cplx acc = cmake(0.0, 0.0);
+    bool done = false;
+    for (int j = 0; j <= ns - 2 && !done; j++) {                                                // :169-181
+        lds_c* cur = (j & 1) ? colB : colA;
+        lds_c* prv = (j & 1) ? colA : colB;
+        const int scur = (j & 1) ? 1 : strideA;
+        const int sprv = (j & 1) ? strideA : 1;
+        for (int m = 1; m <= ns - (j + 1); m++) {
+            cplx hi = lds_ld(cur, m * scur, lane);
+            cplx lo = lds_ld(cur, (m - 1) * scur, lane);
+            cplx denom = csub(hi, lo);
+            if (cabs_(denom) > UCF_EPS) {
+                cplx nw = cadd(lds_ld(prv, m * sprv, lane), rdiv(1.0, denom));
+                lds_st(prv, (m - 1) * sprv, lane, nw);
+            } else {
+                acc = hi;
+                stat = 3;
+                done = true;
+                break;
+            }
+        }
+    }
+    if (!done) acc = lds_ld(colA, 1 * strideA, lane);   // eps(2,ns-2) [ns even] or eps(2,ns-3) [ns odd]: both even columns
+    *status = stat;
+    return acc;
+}
+
+// ------------------------------------------------------------- integration.f90:192-237
+// Per-lane Neville extrapolation to x = 0.  colC[(i*strideC)][lane] holds y(i+1) (destroyed),
+// colD is scratch.  x is wave-uniform.
+UCF_DEV cplx extrap_lane(lds_c* colC, int strideC, lds_c* colD, const double* x, int n, int lane)
+{
+    int ns = 1;
+    for (int i = 2; i <= n; i++) if (x[i - 1] < x[ns - 1]) ns = i;                              // minloc
+    for (int i = 0; i < n; i++) lds_st(colD, i, lane, lds_ld(colC, i * strideC, lane));
+    cplx y = lds_ld(colC, (ns - 1) * strideC, lane);
+    ns = ns - 1;
+    for (int m = 1; m <= n - 1; m++) {
+        for (int i = 1; i <= n - m; i++) {
+            const double dx = x[i - 1] - x[i + m - 1];
+            cplx ci = lds_ld(colC, i * strideC, lane);
+            cplx di = lds_ld(colD, i - 1, lane);
+            cplx den = cdiv(csub(ci, di), cmake(dx, 0.0));                                      // :227 (complex/complex)
+            lds_st(colD, i - 1, lane, rscale(x[i + m - 1], den));
+            lds_st(colC, (i - 1) * strideC, lane, rscale(x[i - 1], den));
+        }
+        cplx dy;
+        if (2 * ns < n - m) {
+            dy = lds_ld(colC, ns * strideC, lane);
+        } else {
+            dy = lds_ld(colD, ns - 1, lane);
+            ns = ns - 1;
+        }
+        y = cadd(y, dy);
+    }
+    return y;
+}
+
+// ------------------------------------------------------------------ the point kernel
+// driver.f90:100-232 for one (t,r) point per wavefront (single-point-run semantics,
+// SURVEY.md quirks Q1 and Q5).
+// LDS per wave (slots of 64 complex):  [R*nz] level sums | [nacc*nz] interval areas |
+// [max(nacc,R)] scratch | FAMILY 4: [2*order] Thomas sweep.
+template <int FAMILY>
+__global__ void __launch_bounds__(UCF_WAVE)
+point_kernel(const ucf_dev_params P, int npts, const double* __restrict__ tDv, const double* __restrict__ rDv,
+             const int* __restrict__ svv, double* __restrict__ hout, double* __restrict__ dhout, ucf_stats* st)
+{
+    extern __shared__ lds_c lds[];
+    const int lane = threadIdx.x;
+    const int nz = P.nz, R = P.R, nacc = P.nacc, N = P.N, ngl = P.ngl;
+    lds_c* accTS = lds;                          // [R][nz]
+    lds_c* accGL = lds + (size_t)R * nz * UCF_WAVE;        // [nacc][nz]
+    lds_c* scr = accGL + (size_t)nacc * nz * UCF_WAVE;     // [max(nacc,R)]
+    lds_c* fdbuf = scr + (size_t)(nacc > R ? nacc : R) * UCF_WAVE;
+
+    bool need_lay1 = false;
+    for (int z = 0; z < nz; z++) need_lay1 |= (P.zLay[z] == 1);
+
+    for (int pt = blockIdx.x; pt < npts; pt += gridDim.x) {
+        const double tD = tDv[pt], rD = rDv[pt];
+        const int sv = svv[pt];
+        const double tee = 2.0 * tD;                                                            // driver.f90:106,217
+        const double sigma = P.alpha - P.logtol / (2.0 * tee);                                  // invlap.f90:165
+        const cplx p = cmake(sigma, UCF_PI * lane / tee);                                       // invlap.f90:168
+        const cplx lt = lap_time(P, p);
+        const double arg = P.j0z[sv - 1] / rD;                                                  // driver.f90:120
+
+        for (int s = 0; s < (R + nacc) * nz; s++) lds_st(lds, s, lane, cmake(0.0, 0.0));
+
+        // ---- finite part: tanh-sinh on [0, arg], all Richardson levels from one pass (:129-157)
+        for (int n = 1; n <= N; n++) {
+            const double a = (P.ts_x[n - 1] * arg) / 2.0;                                       // integration.f90:62
+            const double aj = a * j0(a * rD);                                                   // lhs.f90:118
+            sample_common S;
+            sample_prepare<FAMILY>(P, a, p, need_lay1, S, fdbuf, lane);
+            for (int z = 0; z < nz; z++) {
+                const cplx val = cmul(rscale(aj, sample_z<FAMILY>(P, S, z)), lt);               // lhs.f90:118
+                for (int j = 1; j <= R; j++) {
+                    const int sh = R - j;
+                    if ((n & ((1 << sh) - 1)) == 0) {                                           // driver.f90:150
+                        const double w = P.ts_w[(size_t)(j - 1) * N + ((n >> sh) - 1)];
+                        const int slot = (j - 1) * nz + z;
+                        lds_st(accTS, slot, lane, cadd(lds_ld(accTS, slot, lane), rscale(w, val)));
+                    }
+                }
+            }
+        }
+        // ---- infinite part: Gauss-Lobatto between successive J0 zeros (:187-203)
+        for (int jj = 1; jj <= nacc; jj++) {
+            const double lob = P.j0z[sv + jj - 2] / rD;
+            const double hib = P.j0z[sv + jj - 1] / rD;
+            const double width = hib - lob;
+            for (int m = 0; m < ngl; m++) {
+                const double a = (width * P.gl_x[m] + (hib + lob)) / 2.0;                       // :193
+                const double aj = a * j0(a * rD);
+                const double w = P.gl_w[m];
+                sample_common S;
+                sample_prepare<FAMILY>(P, a, p, need_lay1, S, fdbuf, lane);
+                for (int z = 0; z < nz; z++) {
+                    const cplx val = cmul(rscale(aj, sample_z<FAMILY>(P, S, z)), lt);
+                    const int slot = (jj - 1) * nz + z;
+                    lds_st(accGL, slot, lane, cadd(lds_ld(accGL, slot, lane), cscale(val, w)));  // :201-202
+                }
+            }
+            for (int z = 0; z < nz; z++) {
+                const int slot = (jj - 1) * nz + z;
+                lds_st(accGL, slot, lane, rscale(width / 2.0, lds_ld(accGL, slot, lane)));
+            }
+        }
+        // ---- per depth: Richardson, Wynn-epsilon, de Hoog (:159-230)
+        for (int z = 0; z < nz; z++) {
+            for (int j = 0; j < R; j++) {
+                const int slot = j * nz + z;
+                lds_st(accTS, slot, lane, rscale(arg / 2.0, lds_ld(accTS, slot, lane)));        // :135,154
+            }
+            cplx finint;
+            if (R > 1) finint = extrap_lane(accTS + (size_t)z * UCF_WAVE, nz, scr, P.hv, R, lane);
+            else finint = lds_ld(accTS, z, lane);
+            bool any = false;
+            for (int jj = 0; jj < nacc; jj++) any |= (cabs_(lds_ld(accGL, jj * nz + z, lane)) > 0.0);   // :209
+            cplx infint = cmake(0.0, 0.0);
+            int wst = 0;
+            if (any) infint = wynn_lane(accGL + (size_t)z * UCF_WAVE, nz, scr, nacc, lane, &wst);
+            if (st) {
+                const bool live = lane < P.np;
+                stat_add(&st->wynn_all_zero, live && !any);
+                stat_add(&st->wynn_truncated, live && wst == 1);
+                stat_add(&st->wynn_sentinel, live && wst == 2);
+                stat_add(&st->wynn_early_exit, live && wst == 3);
+            }
+            const cplx totlap = cadd(finint, infint);                                           // :216
+            const double hval = dehoog_wave(totlap, P.M, P.alpha, P.logtol, tD, tee, lane, st);  // :219-223
+            const double dval = dehoog_wave(cmul(totlap, p), P.M, P.alpha, P.logtol, tD, tee, lane, st) * tD;   // :225-230
+            if (lane == 0) {
+                hout[(size_t)pt * nz + z] = hval;
+                dhout[(size_t)pt * nz + z] = dval;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ stage-hook kernels
+// lap_hank_soln for a list of abscissae: block = abscissa, lane = p index; fp[n_a][nz][np]
+template <int FAMILY>
+__global__ void __launch_bounds__(UCF_WAVE)
+samples_kernel(const ucf_dev_params P, int n_a, const double* __restrict__ av, double rD,
+               const double* __restrict__ pv, double* __restrict__ fp)
+{
+    extern __shared__ lds_c lds[];
+    const int lane = threadIdx.x;
+    const int ia = blockIdx.x;
+    if (ia >= n_a) return;
+    const bool live = lane < P.np;
+    const cplx p = live ? cmake(pv[2 * lane], pv[2 * lane + 1]) : cmake(1.0, 0.0);
+    const double a = av[ia];
+    bool need_lay1 = false;
+    for (int z = 0; z < P.nz; z++) need_lay1 |= (P.zLay[z] == 1);
+    const cplx lt = lap_time(P, p);
+    const double aj = a * j0(a * rD);
+    sample_common S;
+    sample_prepare<FAMILY>(P, a, p, need_lay1, S, lds, lane);
+    for (int z = 0; z < P.nz; z++) {
+        const cplx val = cmul(rscale(aj, sample_z<FAMILY>(P, S, z)), lt);
+        if (live) {
+            const size_t o = (((size_t)ia * P.nz + z) * P.np + lane) * 2;
+            fp[o] = val.re;
+            fp[o + 1] = val.im;
+        }
+    }
+}
+
+#if !UCF_FAST
+__global__ void __launch_bounds__(UCF_WAVE)
+dehoog_kernel(int n, int M, double alpha, double logtol, const double* __restrict__ t, const double* __restrict__ tee,
+              const double* __restrict__ fp, double* __restrict__ ft)
+{
+    const int lane = threadIdx.x;
+    const int i = blockIdx.x;
+    if (i >= n) return;
+    const int np = 2 * M + 1;
+    cplx f = (lane < np) ? cmake(fp[((size_t)i * np + lane) * 2], fp[((size_t)i * np + lane) * 2 + 1]) : cmake(0.0, 0.0);
+    const double v = dehoog_wave(f, M, alpha, logtol, t[i], tee[i], lane, nullptr);
+    if (lane == 0) ft[i] = v;
+}
+
+// lane = problem index within the block
+__global__ void __launch_bounds__(UCF_WAVE)
+wynn_kernel(int n, int nterms, const double* __restrict__ series, double* __restrict__ acc, int* __restrict__ status)
+{
+    extern __shared__ lds_c lds[];
+    const int lane = threadIdx.x;
+    const int i = blockIdx.x * UCF_WAVE + lane;
+    lds_c* colA = lds;
+    lds_c* colB = lds + (size_t)nterms * UCF_WAVE;
+    const int ii = i < n ? i : n - 1;
+    for (int k = 0; k < nterms; k++)
+        lds_st(colA, k, lane, cmake(series[((size_t)ii * nterms + k) * 2], series[((size_t)ii * nterms + k) * 2 + 1]));
+    int stt = 0;
+    cplx r = wynn_lane(colA, 1, colB, nterms, lane, &stt);
+    if (i < n) {
+        acc[2 * i] = r.re;
+        acc[2 * i + 1] = r.im;
+        status[i] = stt;
+    }
+}
+
+__global__ void __launch_bounds__(UCF_WAVE)
+extrap_kernel(int n, int R, const double* __restrict__ x, const double* __restrict__ y, double* __restrict__ out)
+{
+    extern __shared__ lds_c lds[];
+    const int lane = threadIdx.x;
+    const int i = blockIdx.x * UCF_WAVE + lane;
+    lds_c* colC = lds;
+    lds_c* colD = lds + (size_t)R * UCF_WAVE;
+    const int ii = i < n ? i : n - 1;
+    for (int k = 0; k < R; k++)
+        lds_st(colC, k, lane, cmake(y[((size_t)ii * R + k) * 2], y[((size_t)ii * R + k) * 2 + 1]));
+    cplx r = extrap_lane(colC, 1, colD, x, R, lane);
+    if (i < n) {
+        out[2 * i] = r.re;
+        out[2 * i + 1] = r.im;
+    }
+}
+#endif
+
+// ------------------------------------------------------------------ launchers
+static inline int family_of(const ucf_dev_params& dp)
+{
+    switch (dp.model) {
+    case 0: return 0;
+    case 1: return 1;
+    case 3: case 4: case 5: return 2;
+    case 6: return dp.MNtype == 1 ? 3 : (dp.MNtype == 2 ? 4 : -1);
+    default: return -1;
+    }
+}
+
+static inline size_t point_lds_bytes(const ucf_dev_params& dp)
+{
+    size_t slots = (size_t)(dp.R + dp.nacc) * dp.nz + (size_t)(dp.nacc > dp.R ? dp.nacc : dp.R);
+    if (family_of(dp) == 4) slots += 2 * (size_t)dp.order;
+    return slots * UCF_WAVE * sizeof(lds_c);
+}
+
+int launch_points(const ucf_dev_params& dp, int npts, const double* d_tD, const double* d_rD, const int* d_sv,
+                  double* d_h, double* d_dh, ucf_stats* d_stats, void* stream)
+{
+    const int fam = family_of(dp);
+    if (fam < 0) return UCF_ERR_UNSUPPORTED;
+    const size_t lds = point_lds_bytes(dp);
+    if (lds > 160 * 1024) return UCF_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(npts), block(UCF_WAVE);
+#define UCF_LAUNCH(F)                                                                                          \
+    do {                                                                                                       \
+        if (lds > 64 * 1024)                                                                                   \
+            (void)hipFuncSetAttribute((const void*)point_kernel<F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL(point_kernel<F>, grid, block, lds, s, dp, npts, d_tD, d_rD, d_sv, d_h, d_dh, d_stats); \
+    } while (0)
+    switch (fam) {
+    case 0: UCF_LAUNCH(0); break;
+    case 1: UCF_LAUNCH(1); break;
+    case 2: UCF_LAUNCH(2); break;
+    case 3: UCF_LAUNCH(3); break;
+    case 4: UCF_LAUNCH(4); break;
+    }
+#undef UCF_LAUNCH
+    return hipGetLastError() == hipSuccess ? UCF_OK : UCF_ERR_HIP;
+}
+
+int launch_samples(const ucf_dev_params& dp, int n_a, const double* d_a, double rD, const double* d_p, double* d_fp,
+                   void* stream)
+{
+    const int fam = family_of(dp);
+    if (fam < 0) return UCF_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    size_t lds = (fam == 4) ? 2 * (size_t)dp.order * UCF_WAVE * sizeof(lds_c) : 16;
+    dim3 grid(n_a), block(UCF_WAVE);
+#define UCF_LAUNCH(F)                                                                                          \
+    do {                                                                                                       \
+        if (lds > 64 * 1024)                                                                                   \
+            (void)hipFuncSetAttribute((const void*)samples_kernel<F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL(samples_kernel<F>, grid, block, lds, s, dp, n_a, d_a, rD, d_p, d_fp);               \
+    } while (0)
+    switch (fam) {
+    case 0: UCF_LAUNCH(0); break;
+    case 1: UCF_LAUNCH(1); break;
+    case 2: UCF_LAUNCH(2); break;
+    case 3: UCF_LAUNCH(3); break;
+    case 4: UCF_LAUNCH(4); break;
+    }
+#undef UCF_LAUNCH
+    return hipGetLastError() == hipSuccess ? UCF_OK : UCF_ERR_HIP;
+}
+
+#if !UCF_FAST
+int launch_dehoog(int n, int M, double alpha, double logtol, const double* d_t, const double* d_tee,
+                  const double* d_fp, double* d_ft, void* stream)
+{
+    hipLaunchKernelGGL(dehoog_kernel, dim3(n), dim3(UCF_WAVE), 0, (hipStream_t)stream, n, M, alpha, logtol, d_t, d_tee,
+                       d_fp, d_ft);
+    return hipGetLastError() == hipSuccess ? UCF_OK : UCF_ERR_HIP;
+}
+int launch_wynn(int n, int nterms, const double* d_series, double* d_acc, int* d_status, void* stream)
+{
+    const size_t lds = 2 * (size_t)nterms * UCF_WAVE * sizeof(lds_c);
+    hipLaunchKernelGGL(wynn_kernel, dim3((n + UCF_WAVE - 1) / UCF_WAVE), dim3(UCF_WAVE), lds, (hipStream_t)stream, n,
+                       nterms, d_series, d_acc, d_status);
+    return hipGetLastError() == hipSuccess ? UCF_OK : UCF_ERR_HIP;
+}
+int launch_extrap(int n, int R, const double* d_x, const double* d_y, double* d_out, void* stream)
+{
+    const size_t lds = 2 * (size_t)R * UCF_WAVE * sizeof(lds_c);
+    hipLaunchKernelGGL(extrap_kernel, dim3((n + UCF_WAVE - 1) / UCF_WAVE), dim3(UCF_WAVE), lds, (hipStream_t)stream, n,
+                       R, d_x, d_y, d_out);
+    return hipGetLastError() == hipSuccess ? UCF_OK : UCF_ERR_HIP;
+}
+#endif
+
+}  // namespace UCF_NS

@@ -1,0 +1,330 @@
+// ucf_math.h -- fp64 complex arithmetic and complex elementary functions for gfx950.
+//
+// The reference's CPU build (flang + compiler-rt + glibc) fixes the semantics that
+// the parity gate is measured against; this header re-implements those semantics
+// as wave-resident device functions:
+//   * complex*complex : plain 4-multiply form (flang inlines it);
+//   * complex/complex, real/complex and complex/real : the scaled division of
+//     compiler-rt's __divdc3 (lib/builtins/divdc3.c): divisor scaled by
+//     2^-ilogb(max(|c|,|d|)), textbook quotient, C99 Annex G recovery cases;
+//   * csqrt / cexp / ccosh / csinh : the case analysis of glibc's
+//     s_csqrt/s_cexp/s_ccosh/s_csinh templates (same thresholds, same overflow
+//     staging with t = 709, same Inf/NaN results) on top of real exp, sincos, cosh,
+//     sinh, hypot.  The in-band rules of the reference (NaN scrub, series
+//     truncation) key on exactly where Inf/NaN appear, so these cases matter.
+//
+// Two build flavours of every kernel include this header:
+//   UCF_FAST == 0  "faithful": compiled with -ffp-contract=off, reference operation
+//                   order everywhere; real functions from the device libm.
+//   UCF_FAST == 1  "fast": FMA contraction allowed, exp-sharing cosh/sinh pairs and
+//                   reciprocal-based division; same case analysis.
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#ifndef UCF_FAST
+#define UCF_FAST 0
+#endif
+
+#define UCF_DEV __device__ __forceinline__
+
+#ifndef UCF_NS
+#error "define UCF_NS (ucf_faithful / ucf_fast) before including ucf_math.h"
+#endif
+namespace UCF_NS {
+namespace ucfm {
+
+struct cplx {
+    double re, im;
+};
+
+UCF_DEV cplx cmake(double re, double im) { cplx z; z.re = re; z.im = im; return z; }
+UCF_DEV cplx cadd(cplx a, cplx b) { return cmake(a.re + b.re, a.im + b.im); }
+UCF_DEV cplx csub(cplx a, cplx b) { return cmake(a.re - b.re, a.im - b.im); }
+UCF_DEV cplx cneg(cplx a) { return cmake(-a.re, -a.im); }
+UCF_DEV cplx cmul(cplx a, cplx b) { return cmake(a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re); }
+UCF_DEV cplx cscale(cplx a, double s) { return cmake(a.re * s, a.im * s); }    // complex*real
+UCF_DEV cplx rscale(double s, cplx a) { return cmake(s * a.re, s * a.im); }    // real*complex
+UCF_DEV cplx caddr(cplx a, double s) { return cmake(a.re + s, a.im); }         // complex+real
+UCF_DEV cplx radd(double s, cplx a) { return cmake(s + a.re, a.im); }          // real+complex
+UCF_DEV cplx rsub(double s, cplx a) { return cmake(s - a.re, -a.im); }         // real-complex
+UCF_DEV cplx csubr(cplx a, double s) { return cmake(a.re - s, a.im); }         // complex-real
+
+UCF_DEV bool d_isnan(double x) { return x != x; }
+UCF_DEV bool d_isinf(double x) { return fabs(x) == __builtin_huge_val(); }
+UCF_DEV bool d_isfinite(double x) { return fabs(x) < __builtin_huge_val(); }
+
+// rare Annex-G recovery of __divdc3, kept out of line of the hot code
+__device__ __noinline__ static cplx cdiv_recover(double a, double b, double c, double d, double denom, bool scaled_inf,
+                                                 cplx z)
+{
+    const double INF = __builtin_huge_val();
+    if ((denom == 0.0) && (!d_isnan(a) || !d_isnan(b))) {
+        z.re = copysign(INF, c) * a;
+        z.im = copysign(INF, c) * b;
+    } else if ((d_isinf(a) || d_isinf(b)) && d_isfinite(c) && d_isfinite(d)) {
+        a = copysign(d_isinf(a) ? 1.0 : 0.0, a);
+        b = copysign(d_isinf(b) ? 1.0 : 0.0, b);
+        z.re = INF * (a * c + b * d);
+        z.im = INF * (b * c - a * d);
+    } else if (scaled_inf && d_isfinite(a) && d_isfinite(b)) {
+        c = copysign(d_isinf(c) ? 1.0 : 0.0, c);
+        d = copysign(d_isinf(d) ? 1.0 : 0.0, d);
+        z.re = 0.0 * (a * c + b * d);
+        z.im = 0.0 * (b * c - a * d);
+    }
+    return z;
+}
+
+// compiler-rt __divdc3
+UCF_DEV cplx cdiv(cplx x, cplx y)
+{
+    double a = x.re, b = x.im, c = y.re, d = y.im;
+    const double m = fmax(fabs(c), fabs(d));          // fmax ignores a NaN operand, like compiler-rt's
+    int il = 0;
+    const bool fin = (m != 0.0) && d_isfinite(m);     // logb(m) finite
+    if (fin) {
+        il = __builtin_amdgcn_frexp_exp(m) - 1;       // == (int)logb(m), subnormals included
+        c = ldexp(c, -il);
+        d = ldexp(d, -il);
+    }
+    const double denom = c * c + d * d;
+    cplx z;
+#if UCF_FAST
+    const double rden = 1.0 / denom;
+    z.re = ldexp((a * c + b * d) * rden, -il);
+    z.im = ldexp((b * c - a * d) * rden, -il);
+#else
+    z.re = ldexp((a * c + b * d) / denom, -il);
+    z.im = ldexp((b * c - a * d) / denom, -il);
+#endif
+    if (__builtin_expect(d_isnan(z.re) && d_isnan(z.im), 0))
+        z = cdiv_recover(a, b, c, d, denom, d_isinf(m), z);
+    return z;
+}
+UCF_DEV cplx rdiv(double s, cplx y) { return cdiv(cmake(s, 0.0), y); }      // real/complex
+UCF_DEV cplx cdivr(cplx x, double s) { return cdiv(x, cmake(s, 0.0)); }     // complex/real (flang -> __divdc3)
+
+UCF_DEV double cabs_(cplx z) { return hypot(z.re, z.im); }
+// utility.f90:59-64
+UCF_DEV bool c_is_finite(cplx z)
+{
+    double m = cabs_(z);
+    return !(d_isnan(m) || m > 1.7976931348623157e308);
+}
+
+// ---------------------------------------------------------------- real helpers
+#define UCF_T709 709             /* (int)((DBL_MAX_EXP-1)*ln2) */
+#define UCF_DBL_MIN 2.2250738585072014e-308
+#define UCF_DBL_MAX 1.7976931348623157e308
+
+UCF_DEV void sincos_(double y, double* s, double* c)
+{
+    if (fabs(y) > UCF_DBL_MIN) {
+        sincos(y, s, c);
+    } else {
+        *s = y;
+        *c = 1.0;
+    }
+}
+
+// cosh(x) and sinh(x) for |x| <= 709
+UCF_DEV void coshsinh_(double x, double* ch, double* sh)
+{
+#if UCF_FAST
+    // one exponential for both; below 0.35 the difference form loses bits in sinh -> series
+    const double ax = fabs(x);
+    const double e = exp(ax);
+    const double ei = 1.0 / e;
+    *ch = 0.5 * (e + ei);
+    double s;
+    if (ax < 0.35) {
+        const double x2 = ax * ax;
+        // sinh x = x (1 + x^2/6 + x^4/120 + ... ) up to x^17 (|x|<0.35: rel err < 1e-18)
+        double pl = 1.0 / 355687428096000.0;
+        pl = pl * x2 + 1.0 / 1307674368000.0;
+        pl = pl * x2 + 1.0 / 6227020800.0;
+        pl = pl * x2 + 1.0 / 39916800.0;
+        pl = pl * x2 + 1.0 / 362880.0;
+        pl = pl * x2 + 1.0 / 5040.0;
+        pl = pl * x2 + 1.0 / 120.0;
+        pl = pl * x2 + 1.0 / 6.0;
+        s = ax + ax * (x2 * pl);
+    } else {
+        s = 0.5 * (e - ei);
+    }
+    *sh = copysign(s, x);
+#else
+    *ch = cosh(x);
+    *sh = sinh(x);
+#endif
+}
+
+// staged overflow handling shared by ccosh/csinh (glibc s_ccosh_template.c / s_csinh_template.c)
+UCF_DEV cplx ch_sh_big_(double absx, double cosix, double sinix)
+{
+    const double exp_t = exp((double)UCF_T709);
+    double rx = absx - UCF_T709;
+    sinix *= exp_t / 2;
+    cosix *= exp_t / 2;
+    if (rx > UCF_T709) {
+        rx -= UCF_T709;
+        sinix *= exp_t;
+        cosix *= exp_t;
+    }
+    if (rx > UCF_T709) return cmake(UCF_DBL_MAX * cosix, UCF_DBL_MAX * sinix);
+    const double ev = exp(rx);
+    return cmake(ev * cosix, ev * sinix);
+}
+
+// ------------------------------------------------------------ complex functions
+// glibc s_ccosh_template.c
+UCF_DEV cplx ccosh_(cplx x)
+{
+    if (__builtin_expect(d_isfinite(x.re) && d_isfinite(x.im), 1)) {
+        double sinix, cosix;
+        sincos_(x.im, &sinix, &cosix);
+        if (__builtin_expect(fabs(x.re) > UCF_T709, 0)) {
+            if (signbit(x.re)) sinix = -sinix;
+            return ch_sh_big_(fabs(x.re), cosix, sinix);
+        }
+        double ch, sh;
+        coshsinh_(x.re, &ch, &sh);
+        return cmake(ch * cosix, sh * sinix);
+    }
+    const double NaN = __builtin_nan("");
+    const double INF = __builtin_huge_val();
+    if (d_isfinite(x.re)) {                     // imaginary part Inf/NaN
+        return cmake(x.im - x.im, (x.re == 0.0) ? 0.0 : NaN);
+    }
+    if (d_isinf(x.re)) {
+        if (d_isfinite(x.im) && x.im != 0.0) {
+            double sinix, cosix;
+            sincos_(x.im, &sinix, &cosix);
+            return cmake(copysign(INF, cosix), copysign(INF, sinix) * copysign(1.0, x.re));
+        }
+        if (x.im == 0.0) return cmake(INF, x.im * copysign(1.0, x.re));
+        return cmake(INF, x.im - x.im);
+    }
+    return cmake(NaN, (x.im == 0.0) ? x.im : NaN);
+}
+
+// glibc s_csinh_template.c
+UCF_DEV cplx csinh_(cplx x)
+{
+    const bool negate = signbit(x.re);
+    const double ax = fabs(x.re);
+    if (__builtin_expect(d_isfinite(ax) && d_isfinite(x.im), 1)) {
+        double sinix, cosix;
+        sincos_(x.im, &sinix, &cosix);
+        if (negate) cosix = -cosix;
+        if (__builtin_expect(ax > UCF_T709, 0)) return ch_sh_big_(ax, cosix, sinix);
+        double ch, sh;
+        coshsinh_(ax, &ch, &sh);
+        return cmake(sh * cosix, ch * sinix);
+    }
+    const double NaN = __builtin_nan("");
+    const double INF = __builtin_huge_val();
+    if (d_isfinite(ax)) {                       // imaginary part Inf/NaN
+        if (ax == 0.0) return cmake(copysign(0.0, negate ? -1.0 : 1.0), x.im - x.im);
+        return cmake(NaN, NaN);
+    }
+    if (d_isinf(ax)) {
+        if (d_isfinite(x.im) && x.im != 0.0) {
+            double sinix, cosix;
+            sincos_(x.im, &sinix, &cosix);
+            double re = copysign(INF, cosix);
+            if (negate) re = -re;
+            return cmake(re, copysign(INF, sinix));
+        }
+        if (x.im == 0.0) return cmake(negate ? -INF : INF, x.im);
+        return cmake(INF, x.im - x.im);
+    }
+    return cmake(NaN, (x.im == 0.0) ? x.im : NaN);
+}
+
+// glibc s_cexp_template.c
+UCF_DEV cplx cexp_(cplx x)
+{
+    if (__builtin_expect(d_isfinite(x.re) && d_isfinite(x.im), 1)) {
+        double sinix, cosix;
+        sincos_(x.im, &sinix, &cosix);
+        double re = x.re;
+        if (__builtin_expect(re > UCF_T709, 0)) {
+            const double exp_t = exp((double)UCF_T709);
+            re -= UCF_T709; sinix *= exp_t; cosix *= exp_t;
+            if (re > UCF_T709) { re -= UCF_T709; sinix *= exp_t; cosix *= exp_t; }
+            if (re > UCF_T709) return cmake(UCF_DBL_MAX * cosix, UCF_DBL_MAX * sinix);
+        }
+        const double ev = exp(re);
+        return cmake(ev * cosix, ev * sinix);
+    }
+    const double NaN = __builtin_nan("");
+    const double INF = __builtin_huge_val();
+    if (d_isfinite(x.re)) return cmake(NaN, NaN);
+    if (d_isinf(x.re)) {
+        if (d_isfinite(x.im)) {
+            const double value = signbit(x.re) ? 0.0 : INF;
+            if (x.im == 0.0) return cmake(value, x.im);
+            double sinix, cosix;
+            sincos_(x.im, &sinix, &cosix);
+            return cmake(copysign(value, cosix), copysign(value, sinix));
+        }
+        if (!signbit(x.re)) return cmake(INF, x.im - x.im);
+        return cmake(0.0, copysign(0.0, x.im));
+    }
+    return cmake(NaN, (x.im == 0.0) ? x.im : NaN);
+}
+
+// glibc s_csqrt_template.c
+UCF_DEV cplx csqrt_(cplx x)
+{
+    double re = x.re, im = x.im;
+    if (__builtin_expect(d_isfinite(re) && d_isfinite(im) && re != 0.0 && im != 0.0, 1)) {
+        int scale = 0;
+        if (__builtin_expect(fabs(re) > UCF_DBL_MAX / 4, 0)) {
+            scale = 1; re = ldexp(re, -2); im = ldexp(im, -2);
+        } else if (__builtin_expect(fabs(im) > UCF_DBL_MAX / 4, 0)) {
+            scale = 1;
+            re = (fabs(re) >= 4 * UCF_DBL_MIN) ? ldexp(re, -2) : 0.0;
+            im = ldexp(im, -2);
+        } else if (__builtin_expect(fabs(re) < 2 * UCF_DBL_MIN && fabs(im) < 2 * UCF_DBL_MIN, 0)) {
+            scale = -((53 + 1) / 2);
+            re = ldexp(re, -2 * scale); im = ldexp(im, -2 * scale);
+        }
+        const double d = hypot(re, im);
+        double r, s;
+        if (re > 0) {
+            r = sqrt(0.5 * (d + re));
+            if (scale == 1 && fabs(im) < 1) { s = im / r; r = ldexp(r, scale); scale = 0; }
+            else s = 0.5 * (im / r);
+        } else {
+            s = sqrt(0.5 * (d - re));
+            if (scale == 1 && fabs(im) < 1) { r = fabs(im / s); s = ldexp(s, scale); scale = 0; }
+            else r = fabs(0.5 * (im / s));
+        }
+        if (scale) { r = ldexp(r, scale); s = ldexp(s, scale); }
+        return cmake(r, copysign(s, x.im));
+    }
+    const double NaN = __builtin_nan("");
+    const double INF = __builtin_huge_val();
+    if (!(d_isfinite(re) && d_isfinite(im))) {
+        if (d_isinf(im)) return cmake(INF, im);
+        if (d_isinf(re)) {
+            if (re < 0) return cmake(d_isnan(im) ? NaN : 0.0, copysign(INF, im));
+            return cmake(re, d_isnan(im) ? NaN : copysign(0.0, im));
+        }
+        return cmake(NaN, NaN);
+    }
+    if (im == 0.0) {
+        if (re < 0) return cmake(0.0, copysign(sqrt(-re), im));
+        return cmake(fabs(sqrt(re)), copysign(0.0, im));
+    }
+    // re == 0
+    double r;
+    if (fabs(im) >= 2 * UCF_DBL_MIN) r = sqrt(0.5 * fabs(im));
+    else r = 0.5 * sqrt(2 * fabs(im));
+    return cmake(r, copysign(r, im));
+}
+
+}  // namespace ucfm
+}  // namespace UCF_NS

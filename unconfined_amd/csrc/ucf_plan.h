@@ -1,0 +1,68 @@
+// ucf_plan.h -- internal structures shared by the host API and the kernels.
+#pragma once
+#include "../../include/ucf.h"
+
+#define UCF_WAVE 64
+#define UCF_MAX_R 16
+
+// Everything a kernel needs, passed by value as one kernel argument (lives in
+// SGPRs / the scalar cache: it is wave-uniform).  Table pointers are device
+// pointers into one small per-plan allocation that stays L2/scalar-cache hot.
+struct ucf_dev_params {
+    int model, MNtype, order, timeType, MoenchM;
+    int M, np, k, N, R, nacc, ngl, nz;
+    int nj0z, _pad;
+    double timePar[2];
+    double kappa, alphaD, beta;
+    double lD, dD, bD, dD1, lD1;              // dD1 = 1-dD, lD1 = 1-lD (laplace_hankel_solutions.f90:157-158)
+    double MoenchInvGamma[UCF_MAX_MOENCH];    // 1.0/gamma_m (:74)
+    double alpha, logtol, maxexp;
+    // Mishra/Neuman (Malama form, :404-442): host-evaluated scalar prefactors
+    double mn_vartheta, mn_u0;
+    // Mishra/Neuman FD (:444-544)
+    double fd_h, fd_invhsq, fd_beta0, fd_beta3, fd_expmb2;   // exp(-beta2)
+    double hv[UCF_MAX_R];                     // Richardson spacings (driver.f90:91)
+    double zD[UCF_MAX_NZ];
+    int zLay[UCF_MAX_NZ];
+    const double* ts_x;    // [N]      tanh(u2)+1 of the densest level (integration.f90:62 without *s/2)
+    const double* ts_w;    // [R][N]   normalised weights of level j in row j-1 (first Nv(j) entries)
+    const double* gl_x;    // [ngl]
+    const double* gl_w;    // [ngl]
+    const double* j0z;     // [nj0z]
+    const double* fd_e;    // [order]  exp(-beta1*(j-1)*h)
+};
+
+struct ucf_plan {
+    ucf_params P;
+    ucf_derived D;
+    ucf_dev_params dev;        // zD/zLay/nz filled per call
+    int mode;                  // 0 faithful, 1 fast
+    int device;
+    double* d_tables;          // one allocation holding all tables
+    size_t tables_bytes;
+    // host copies (for the accessor API)
+    double* h_j0z;
+    double* h_ts_x;
+    double* h_ts_w;            // [R][N]
+    double* h_gl_x;
+    double* h_gl_w;
+    int Nv[UCF_MAX_R];
+};
+
+// launchers implemented in ucf_kernels.hip (one set per build flavour)
+namespace ucf_faithful {
+int launch_points(const ucf_dev_params& dp, int npts, const double* d_tD, const double* d_rD, const int* d_sv,
+                  double* d_h, double* d_dh, ucf_stats* d_stats, void* stream);
+int launch_samples(const ucf_dev_params& dp, int n_a, const double* d_a, double rD, const double* d_p, double* d_fp,
+                   void* stream);
+int launch_dehoog(int n, int M, double alpha, double logtol, const double* d_t, const double* d_tee,
+                  const double* d_fp, double* d_ft, void* stream);
+int launch_wynn(int n, int nterms, const double* d_series, double* d_acc, int* d_status, void* stream);
+int launch_extrap(int n, int R, const double* d_x, const double* d_y, double* d_out, void* stream);
+}
+namespace ucf_fast {
+int launch_points(const ucf_dev_params& dp, int npts, const double* d_tD, const double* d_rD, const int* d_sv,
+                  double* d_h, double* d_dh, ucf_stats* d_stats, void* stream);
+int launch_samples(const ucf_dev_params& dp, int n_a, const double* d_a, double rD, const double* d_p, double* d_fp,
+                   void* stream);
+}

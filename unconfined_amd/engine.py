@@ -1,0 +1,237 @@
+"""Host-side mirror of the reference's operator interface for the drawdown path.
+
+The reference has no library API; its de-facto interface is the set of module
+procedures ``program Driver`` imports (reference driver.f90:28-40).  The same
+names are offered here on top of the C ABI:
+
+    Plan(params)                       read_input's numerical half + first-time setup
+    Plan.drawdown(tD, rD, sv, zD, zLay)  the (i,k) loop body, driver.f90:100-232
+    Plan.lap_hank_soln / pvalues / ...  the imported procedures, for stage parity
+    run_deck(path)                     program Driver for one deck (time-series or contour)
+
+Everything numerical happens in libucf.so on the GPU (or, for the once-per-run
+table setup, in its host code); this module only marshals arrays.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import lib as _libmod
+from .abi import UcfDerived, UcfParams, UcfStats, params_from_deck
+from .deck import Deck, SpaceSpec, TimeSpec, resolve
+from .host import screen_average_np
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+class Plan:
+    """Immutable per-parameter-set state: dimensionless parameters, J0 zeros,
+    tanh-sinh / Gauss-Lobatto tables (resident on the GPU)."""
+
+    def __init__(self, params: UcfParams, mode: str = "faithful"):
+        self._lib = _libmod.load()
+        self._h = C.c_void_p()
+        self.params = params
+        _libmod.check(self._lib.ucf_plan_create(C.byref(params), C.byref(self._h)))
+        self.derived = UcfDerived()
+        _libmod.check(self._lib.ucf_plan_derived(self._h, C.byref(self.derived)))
+        self.set_mode(mode)
+
+    @classmethod
+    def from_deck(cls, dk: Deck, mode: str = "faithful") -> "Plan":
+        return cls(params_from_deck(dk), mode)
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.ucf_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_mode(self, mode: str):
+        m = {"faithful": 0, "fast": 1}[mode]
+        _libmod.check(self._lib.ucf_plan_set_mode(self._h, m))
+        self.mode = mode
+
+    # ---- tables (read back for parity tests / headers)
+    def j0z(self) -> np.ndarray:
+        out = np.zeros(self.derived.nj0z)
+        _libmod.check(self._lib.ucf_plan_j0z(self._h, len(out), out))
+        return out
+
+    def tanh_sinh(self, level: int) -> Tuple[np.ndarray, Optional[np.ndarray]]:
+        P = self.params
+        n = 2 ** (P.k - P.R + level) - 1
+        w = np.zeros(n)
+        x = np.zeros(n) if level == P.R else None
+        _libmod.check(self._lib.ucf_plan_tanh_sinh(self._h, level, n, w, x.ctypes.data if x is not None else None))
+        return w, x
+
+    def gauss_lobatto(self):
+        n = self.params.ord - 2
+        x, w = np.zeros(n), np.zeros(n)
+        _libmod.check(self._lib.ucf_plan_gauss_lobatto(self._h, n, x, w))
+        return x, w
+
+    # ---- host helpers
+    def zlay(self, zD) -> np.ndarray:
+        zD = _f64(zD)
+        out = np.zeros(len(zD), np.int32)
+        _libmod.check(self._lib.ucf_zlay(self._h, len(zD), zD, out))
+        return out
+
+    def split_vector(self, tD) -> np.ndarray:
+        tD = _f64(tD)
+        out = np.zeros(len(tD), np.int32)
+        _libmod.check(self._lib.ucf_split_vector(self._h, len(tD), tD, out))
+        return out
+
+    def pvalues(self, tee: float) -> np.ndarray:
+        out = np.zeros((self.derived.np, 2))
+        _libmod.check(self._lib.ucf_pvalues(self._h, float(tee), out))
+        return out
+
+    # ---- the hot path
+    def drawdown(self, tD, rD, sv, zD, zLay, with_stats: bool = False):
+        """h, dh of shape [npts, nz] (dimensionless, before screen averaging)"""
+        tD, rD, sv, zD, zLay = _f64(tD), _f64(rD), _i32(sv), _f64(zD), _i32(zLay)
+        n, nz = len(tD), len(zD)
+        if len(rD) != n or len(sv) != n or len(zLay) != nz:
+            raise ValueError("tD, rD, sv must have equal length; zD, zLay too")
+        h = np.zeros((n, nz))
+        dh = np.zeros((n, nz))
+        st = UcfStats()
+        _libmod.check(self._lib.ucf_drawdown_batch(self._h, n, tD, rD, sv, nz, zD, zLay, h, dh,
+                                                   C.byref(st) if with_stats else None))
+        if with_stats:
+            return h, dh, {k: getattr(st, k) for k, _ in UcfStats._fields_}
+        return h, dh
+
+    def drawdown_device(self, n: int, d_tD: int, d_rD: int, d_sv: int, zD, zLay, d_h: int, d_dh: int,
+                        stream: int = 0, d_stats: int = 0):
+        """asynchronous launch on device pointers (ints), e.g. torch tensors' data_ptr()"""
+        zD, zLay = _f64(zD), _i32(zLay)
+        _libmod.check(self._lib.ucf_drawdown_batch_device(self._h, int(n), d_tD, d_rD, d_sv, len(zD), zD, zLay,
+                                                          d_h, d_dh, d_stats or None, stream or None))
+
+    # ---- stage hooks
+    def lap_hank_soln(self, a, rD: float, p, zD, zLay) -> np.ndarray:
+        """fp[n_a, nz, np, 2]"""
+        a, p, zD, zLay = _f64(np.atleast_1d(a)), _f64(p), _f64(zD), _i32(zLay)
+        out = np.zeros((len(a), len(zD), p.shape[0], 2))
+        _libmod.check(self._lib.ucf_eval_samples(self._h, len(a), a, float(rD), p.shape[0], p, len(zD), zD, zLay, out))
+        return out
+
+
+def dehoog(M: int, alpha: float, tol: float, t, tee, fp) -> np.ndarray:
+    lib = _libmod.load()
+    t, tee, fp = _f64(np.atleast_1d(t)), _f64(np.atleast_1d(tee)), _f64(fp)
+    n = len(t)
+    out = np.zeros(n)
+    _libmod.check(lib.ucf_dehoog(n, M, alpha, tol, t, tee, fp.reshape(n, 2 * M + 1, 2), out))
+    return out
+
+
+def wynn_epsilon(series):
+    """series[n, nterms, 2] -> (acc[n,2], status[n])"""
+    lib = _libmod.load()
+    s = _f64(series)
+    n, nt = s.shape[0], s.shape[1]
+    acc = np.zeros((n, 2))
+    st = np.zeros(n, np.int32)
+    _libmod.check(lib.ucf_wynn_epsilon(n, nt, s, acc, st))
+    return acc, st
+
+
+def extraptozero(x, y):
+    """x[R], y[n, R, 2] -> out[n, 2]"""
+    lib = _libmod.load()
+    x, y = _f64(x), _f64(y)
+    n, R = y.shape[0], y.shape[1]
+    out = np.zeros((n, 2))
+    _libmod.check(lib.ucf_extraptozero(n, R, x, y, out))
+    return out
+
+
+def fp64_fma_peak() -> float:
+    lib = _libmod.load()
+    v = C.c_double(0.0)
+    _libmod.check(lib.ucf_fp64_fma_peak(C.byref(v)))
+    return v.value
+
+
+def logspace(lo: int, hi: int, n: int) -> np.ndarray:
+    out = np.zeros(n)
+    _libmod.check(_libmod.load().ucf_logspace(lo, hi, n, out))
+    return out
+
+
+def linspace(lo: float, hi: float, n: int) -> np.ndarray:
+    out = np.zeros(n)
+    _libmod.check(_libmod.load().ucf_linspace(lo, hi, n, out))
+    return out
+
+
+# ----------------------------------------------------------------------------- program Driver
+class DeckResult:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def grids_from_deck(dk: Deck, deck_path: Optional[str] = None, ts: Optional[TimeSpec] = None,
+                    sp: Optional[SpaceSpec] = None):
+    """times, radii, depths as read_input builds them (driver_io.f90:385-523)"""
+    if dk.timeseries:
+        if ts is None:
+            ts = TimeSpec.read(resolve(deck_path or ".", dk.timeFileName))
+        t = logspace(ts.min_log, ts.max_log, ts.n) if ts.compute else _f64(ts.times)
+        r = np.array([dk.rval])
+        z = linspace(dk.zBot, dk.zTop, 1 if dk.piezometer else dk.zOrd)
+    else:
+        if sp is None:
+            sp = SpaceSpec.read(resolve(deck_path or ".", dk.spaceFileName))
+        t = np.array([dk.tval])
+        if sp.compute:
+            r = linspace(sp.min_r, sp.max_r, sp.n_r)
+            z = linspace(sp.min_z, sp.max_z, sp.n_z)
+        else:
+            r, z = _f64(sp.r), _f64(sp.z)
+    return t, r, z
+
+
+def run_deck(deck_path: str, mode: str = "faithful") -> DeckResult:
+    """what `./unconfined deck` computes: rows of (t, h, dh) for a time series or
+    (z, r, h, dh) for a contour map, dimensional unless the deck says dimensionless.
+    Contour mode uses each radius' own tanh-sinh interval (SURVEY.md quirk Q1 fixed)."""
+    dk = Deck.read(deck_path)
+    plan = Plan.from_deck(dk, mode)
+    D = plan.derived
+    t, r, z = grids_from_deck(dk, deck_path)
+    tD, rD, zD = t / D.Tc, r / D.Lc, z / D.Lc
+    zl = plan.zlay(zD)
+    sv_t = plan.split_vector(tD)
+    TT, RR = np.meshgrid(tD, rD, indexing="ij")
+    SV = np.repeat(sv_t[:, None], len(rD), axis=1)
+    h, dh = plan.drawdown(TT.ravel(), RR.ravel(), SV.ravel(), zD, zl)
+    sc = 1.0 if dk.dimless else D.Hc
+    if dk.timeseries:
+        hobs = screen_average_np(h, dk) * sc
+        dobs = screen_average_np(dh, dk) * sc
+        return DeckResult(deck=dk, plan=plan, t=(tD if dk.dimless else t), h=hobs, dh=dobs, raw_h=h, raw_dh=dh)
+    nt, nr, nz = len(tD), len(rD), len(zD)
+    return DeckResult(deck=dk, plan=plan, z=(zD if dk.dimless else z), r=(rD if dk.dimless else r),
+                      h=(h * sc).reshape(nt, nr, nz), dh=(dh * sc).reshape(nt, nr, nz))

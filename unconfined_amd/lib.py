@@ -1,0 +1,96 @@
+"""ctypes binding of the product library ``unconfined_amd/libucf.so`` (the C ABI of
+include/ucf.h: HIP kernels for gfx950 + host-side plan builder).
+
+There is deliberately no fallback: if the shared library is missing or no HIP
+device is usable, every compute entry point raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from .abi import UcfDerived, UcfParams, UcfStats
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libucf.so")
+
+_dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+_ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+
+EXPORTS = [
+    "ucf_version", "ucf_last_error", "ucf_status_string",
+    "ucf_plan_create", "ucf_plan_destroy", "ucf_plan_derived", "ucf_plan_j0z", "ucf_plan_tanh_sinh",
+    "ucf_plan_gauss_lobatto", "ucf_plan_set_mode",
+    "ucf_logspace", "ucf_linspace", "ucf_zlay", "ucf_split_vector",
+    "ucf_drawdown_batch", "ucf_drawdown_batch_device", "ucf_screen_average",
+    "ucf_eval_samples", "ucf_pvalues", "ucf_dehoog", "ucf_wynn_epsilon", "ucf_extraptozero",
+    "ucf_fp64_fma_peak",
+]
+
+
+class UcfError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"ucf status {status}: {message}")
+        self.status = status
+        self.message = message
+
+
+def build(verbose: bool = False) -> str:
+    """compile the HIP library in-tree (hipcc, gfx950); returns the .so path"""
+    res = subprocess.run(["make", "-C", os.path.join(HERE, "csrc"), "-j4"], capture_output=True, text=True)
+    if verbose or res.returncode:
+        print(res.stdout[-4000:])
+        print(res.stderr[-4000:])
+    if res.returncode:
+        raise RuntimeError("building libucf.so failed")
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(there is no CPU fallback for the drawdown path)")
+    lib = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    lib.ucf_version.restype = C.c_int
+    lib.ucf_last_error.restype = C.c_char_p
+    lib.ucf_status_string.restype = C.c_char_p
+    lib.ucf_status_string.argtypes = [C.c_int]
+    lib.ucf_plan_create.argtypes = [C.POINTER(UcfParams), C.POINTER(vp)]
+    lib.ucf_plan_destroy.argtypes = [vp]
+    lib.ucf_plan_destroy.restype = None
+    lib.ucf_plan_derived.argtypes = [vp, C.POINTER(UcfDerived)]
+    lib.ucf_plan_j0z.argtypes = [vp, C.c_int, _dp]
+    lib.ucf_plan_tanh_sinh.argtypes = [vp, C.c_int, C.c_int, _dp, vp]
+    lib.ucf_plan_gauss_lobatto.argtypes = [vp, C.c_int, _dp, _dp]
+    lib.ucf_plan_set_mode.argtypes = [vp, C.c_int]
+    lib.ucf_logspace.argtypes = [C.c_int, C.c_int, C.c_int, _dp]
+    lib.ucf_linspace.argtypes = [C.c_double, C.c_double, C.c_int, _dp]
+    lib.ucf_zlay.argtypes = [vp, C.c_int, _dp, _ip]
+    lib.ucf_split_vector.argtypes = [vp, C.c_int, _dp, _ip]
+    lib.ucf_drawdown_batch.argtypes = [vp, C.c_int, _dp, _dp, _ip, C.c_int, _dp, _ip, _dp, _dp, C.POINTER(UcfStats)]
+    lib.ucf_drawdown_batch_device.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int, _dp, _ip, vp, vp, vp, vp]
+    lib.ucf_screen_average.argtypes = [C.c_int, C.c_int, _dp, _dp]
+    lib.ucf_eval_samples.argtypes = [vp, C.c_int, _dp, C.c_double, C.c_int, _dp, C.c_int, _dp, _ip, _dp]
+    lib.ucf_pvalues.argtypes = [vp, C.c_double, _dp]
+    lib.ucf_dehoog.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, _dp, _dp, _dp, _dp]
+    lib.ucf_wynn_epsilon.argtypes = [C.c_int, C.c_int, _dp, _dp, _ip]
+    lib.ucf_extraptozero.argtypes = [C.c_int, C.c_int, _dp, _dp, _dp]
+    lib.ucf_fp64_fma_peak.argtypes = [C.POINTER(C.c_double)]
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        lib = load()
+        raise UcfError(rc, (lib.ucf_last_error() or b"").decode() or lib.ucf_status_string(rc).decode())
