@@ -154,6 +154,16 @@ int ucf_drawdown_batch_device(ucf_plan* plan, int npts,
                               int nz, const double* zD, const int* zLay,
                               double* d_h, double* d_dh, ucf_stats* d_stats, void* stream);
 
+/* The same loop body over the product grid the reference's driver actually walks
+ * (do i = 1,nt / do k = 1,nr, driver.f90:100,113): nt times (tD[i], sv[i]) x nr radii rD[k].
+ * Outputs [nt][nr][nz] row-major.  Abscissae and a*J0(a*rD) depend only on (rD, sv) and are
+ * computed once per radius here instead of once per point. */
+int ucf_drawdown_grid(ucf_plan* plan, int nt, const double* tD, const int* sv, int nr, const double* rD,
+                      int nz, const double* zD, const int* zLay, double* h, double* dh, ucf_stats* stats);
+int ucf_drawdown_grid_device(ucf_plan* plan, int nt, const double* d_tD, const int* d_sv, int nr, const double* d_rD,
+                             int nz, const double* zD, const int* zLay, double* d_h, double* d_dh,
+                             ucf_stats* d_stats, void* stream);
+
 /* driver.f90:234-243 (quirk Q2: not a textbook trapezoid) */
 int ucf_screen_average(int npts, int zOrd, const double* h, double* havg);
 

@@ -79,7 +79,9 @@ for name in names:
         if e2e is None: continue
         t = O.logspace(ts.min_log, ts.max_log, ts.n); tD = t / D.Tc
         sv = O.split_vector(list(dk.j0s), tD)
-        idx = np.unique(np.linspace(0, len(t) - 1, 24).astype(int))
+        NSUB = {"c2_neuman74_fullpen": 32, "c3_moench": 24, "c4_malama_partpen": 24, "c5_mishra_fd64": 12,
+                "malama_k10": 8, "mishra_malama": 8, "mishra_fd30": 16}
+        idx = np.unique(np.linspace(0, len(t) - 1, NSUB.get(name, 24)).astype(int))
         for ir in range(len(e2e["radii"])):
             rD = np.full(len(idx), e2e["radii"][ir] / D.Lc)
             t0 = time.time()
@@ -89,6 +91,16 @@ for name in names:
                 print("   drawdown failed:", e); break
             dt = time.time() - t0
             ho, dho = O.batch(P, tD[idx], rD, sv[idx], zD, zl)
-            eh = np.abs(h - ho) / np.maximum(np.abs(ho), 1e-3 / (1 if dk.dimless else D.Hc))
-            ed = np.abs(dh - dho) / np.maximum(np.abs(dho), 1e-3 / (1 if dk.dimless else D.Hc))
-            print(f"   {mode} r={e2e['radii'][ir]:8.3f}: e2e vs oracle h {eh.max():.2e} dh {ed.max():.2e}  ({dt*1e3:.0f} ms) stats {[v for v in st.values()]}", flush=True)
+            fl = 1e-3 / (1 if dk.dimless else D.Hc)
+            eh = np.abs(h - ho) / np.maximum(np.abs(ho), fl)
+            ed = np.abs(dh - dho) / np.maximum(np.abs(dho), fl)
+            msg = ""
+            tp = os.path.join(GOLD, f"truth_{name}.npz")
+            if os.path.exists(tp):
+                tr = np.load(tp)
+                if np.array_equal(tr["idx"], idx):
+                    ht, dht = tr[f"h_r{ir}"], tr[f"dh_r{ir}"]
+                    f = lambda x, y: (np.abs(x - y) / np.maximum(np.abs(y), fl))
+                    msg = (f" | vs truth: gpu h {f(h,ht).max():.1e}/{np.median(f(h,ht)):.1e} ref h {f(ho,ht).max():.1e}/{np.median(f(ho,ht)):.1e}"
+                           f" gpu dh {f(dh,dht).max():.1e}/{np.median(f(dh,dht)):.1e} ref dh {f(dho,dht).max():.1e}/{np.median(f(dho,dht)):.1e}")
+            print(f"   {mode} r={e2e['radii'][ir]:8.3f}: vs oracle h {eh.max():.2e} dh {ed.max():.2e} ({dt*1e3:.0f} ms){msg}", flush=True)

@@ -321,6 +321,13 @@ int ucf_plan_create(const ucf_params* Pin, ucf_plan** out)
     dp.lD = D.lD; dp.dD = D.dD; dp.bD = D.bD; dp.dD1 = 1.0 - D.dD; dp.lD1 = 1.0 - D.lD;
     for (int m = 0; m < P.MoenchM; m++) dp.MoenchInvGamma[m] = 1.0 / D.MoenchGamma[m];
     dp.alpha = P.alpha; dp.logtol = std::log(P.tol); dp.maxexp = -std::log(DBL_EPSILON) / 3.0;   // constants.f90:66
+    dp.inv_kappa = 1.0 / P.kappa;
+    dp.inv_bD = 1.0 / D.bD;
+    dp.fold_dD = (D.dD == 0.0);                       // sinh(eta*0) == 0 exactly
+    dp.fold_lD1 = (dp.lD1 == 0.0);
+    dp.share_g1top = ((dp.dD1 - 1.0) == -D.dD);       // cosh(eta*(dD1-1)) == cosh(eta*dD) bit for bit
+    // no cosh/sinh (<= e^{Re eta}) nor product of two of them (<= e^{2 Re eta}) may overflow on the fast path
+    dp.fast_eta_max = (dp.fold_dD && dp.fold_lD1) ? 700.0 : 350.0;
     dp.ts_x = pl->d_tables + o_tsx;
     dp.ts_w = pl->d_tables + o_tsw;
     dp.gl_x = pl->d_tables + o_glx;
@@ -336,6 +343,7 @@ void ucf_plan_destroy(ucf_plan* pl)
 {
     if (!pl) return;
     if (pl->d_tables) (void)hipFree(pl->d_tables);
+    if (pl->d_work) (void)hipFree(pl->d_work);
     std::free(pl->h_j0z); std::free(pl->h_ts_x); std::free(pl->h_ts_w); std::free(pl->h_gl_x); std::free(pl->h_gl_w);
     delete pl;
 }
@@ -447,6 +455,60 @@ int ucf_screen_average(int npts, int zOrd, const double* h, double* havg)
 }
 
 // ---- the hot path
+namespace {
+
+// abscissa-table workspace: nrows x nabs x (a, a*J0) doubles
+int ensure_work(ucf_plan* pl, size_t bytes)
+{
+    if (pl->work_bytes >= bytes) return UCF_OK;
+    if (pl->d_work) {
+        (void)hipDeviceSynchronize();      // a previous launch may still read the old table
+        (void)hipFree(pl->d_work);
+        pl->d_work = nullptr;
+        pl->work_bytes = 0;
+    }
+    if (hipMalloc((void**)&pl->d_work, bytes) != hipSuccess) return fail(UCF_ERR_NOMEM, "hipMalloc of %zu workspace bytes failed", bytes);
+    pl->work_bytes = bytes;
+    return UCF_OK;
+}
+
+int launch_points_any(ucf_plan* pl, const ucf_dev_params& dp, int npts, int per_point, int nr, int nsv, int svmin,
+                      const double* d_tD, const double* d_rD, const int* d_sv, double* d_h, double* d_dh,
+                      ucf_stats* d_stats, void* stream)
+{
+    int rc = (pl->mode == 1)
+                 ? ucf_fast::launch_points(dp, npts, per_point, nr, nsv, svmin, d_tD, d_rD, d_sv, pl->d_work, d_h, d_dh, d_stats, stream)
+                 : ucf_faithful::launch_points(dp, npts, per_point, nr, nsv, svmin, d_tD, d_rD, d_sv, pl->d_work, d_h, d_dh, d_stats, stream);
+    if (rc == UCF_ERR_UNSUPPORTED) return fail(rc, "this model / size combination has no kernel (model %d, LDS limit)", dp.model);
+    if (rc) return fail(rc, "kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+    return UCF_OK;
+}
+
+}  // namespace
+
+int ucf_drawdown_grid_device(ucf_plan* pl, int nt, const double* d_tD, const int* d_sv, int nr, const double* d_rD,
+                             int nz, const double* zD, const int* zLay, double* d_h, double* d_dh,
+                             ucf_stats* d_stats, void* stream)
+{
+    if (!pl) return fail(UCF_ERR_BAD_ARGUMENT, "NULL plan");
+    if (nt < 0 || nr < 0) return fail(UCF_ERR_BAD_ARGUMENT, "negative grid size");
+    if (nt == 0 || nr == 0) return UCF_OK;
+    if ((long long)nt * nr > 0x7fffffffLL) return fail(UCF_ERR_BAD_ARGUMENT, "grid larger than 2^31-1 points: split it");
+    if (!d_tD || !d_rD || !d_sv || !d_h || !d_dh) return fail(UCF_ERR_BAD_ARGUMENT, "NULL device array");
+    ucf_dev_params dp;
+    int rc = fill_call_params(pl, nz, zD, zLay, dp);
+    if (rc) return rc;
+    const int* j0s = pl->P.j0s;
+    const int svmin = j0s[0] < j0s[1] ? j0s[0] : j0s[1];
+    const int nsv = (j0s[0] > j0s[1] ? j0s[0] - j0s[1] : j0s[1] - j0s[0]) + 1;     // driver_io.f90:660-664: sv in [min,max]
+    const size_t nabs = (size_t)pl->D.nabs;
+    rc = ensure_work(pl, (size_t)nr * nsv * nabs * 2 * sizeof(double));
+    if (rc) return rc;
+    rc = ucf_faithful::launch_abscissae(dp, nr * nsv, 0, nsv, svmin, d_rD, d_sv, pl->d_work, stream);
+    if (rc) return fail(rc, "abscissa kernel launch failed");
+    return launch_points_any(pl, dp, nt * nr, 0, nr, nsv, svmin, d_tD, d_rD, d_sv, d_h, d_dh, d_stats, stream);
+}
+
 int ucf_drawdown_batch_device(ucf_plan* pl, int npts, const double* d_tD, const double* d_rD, const int* d_sv,
                               int nz, const double* zD, const int* zLay, double* d_h, double* d_dh,
                               ucf_stats* d_stats, void* stream)
@@ -458,12 +520,33 @@ int ucf_drawdown_batch_device(ucf_plan* pl, int npts, const double* d_tD, const 
     ucf_dev_params dp;
     int rc = fill_call_params(pl, nz, zD, zLay, dp);
     if (rc) return rc;
-    rc = (pl->mode == 1) ? ucf_fast::launch_points(dp, npts, d_tD, d_rD, d_sv, d_h, d_dh, d_stats, stream)
-                         : ucf_faithful::launch_points(dp, npts, d_tD, d_rD, d_sv, d_h, d_dh, d_stats, stream);
-    if (rc == UCF_ERR_UNSUPPORTED) return fail(rc, "this model / size combination has no kernel (model %d, LDS limit)", dp.model);
-    if (rc) return fail(rc, "kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+    // arbitrary points: one table row per point, in chunks that keep the workspace <= 256 MiB
+    const size_t row_bytes = (size_t)pl->D.nabs * 2 * sizeof(double);
+    int chunk = (int)((256u << 20) / row_bytes);
+    if (chunk < 1) chunk = 1;
+    if (chunk > npts) chunk = npts;
+    rc = ensure_work(pl, (size_t)chunk * row_bytes);
+    if (rc) return rc;
+    for (int base = 0; base < npts; base += chunk) {
+        const int n = (npts - base < chunk) ? npts - base : chunk;
+        rc = ucf_faithful::launch_abscissae(dp, n, 1, 1, 0, d_rD + base, d_sv + base, pl->d_work, stream);
+        if (rc) return fail(rc, "abscissa kernel launch failed");
+        rc = launch_points_any(pl, dp, n, 1, 1, 1, 0, d_tD + base, d_rD + base, d_sv + base, d_h + (size_t)base * nz,
+                               d_dh + (size_t)base * nz, d_stats, stream);
+        if (rc) return rc;
+    }
     return UCF_OK;
 }
+
+namespace {
+int check_sv(const ucf_plan* pl, int n, const int* sv)
+{
+    for (int i = 0; i < n; i++)
+        if (sv[i] < 1 || sv[i] + pl->P.nacc > pl->D.nj0z)
+            return fail(UCF_ERR_BAD_ARGUMENT, "sv[%d]=%d outside 1..%d", i, sv[i], pl->D.nj0z - pl->P.nacc);
+    return UCF_OK;
+}
+}  // namespace
 
 int ucf_drawdown_batch(ucf_plan* pl, int npts, const double* tD, const double* rD, const int* sv,
                        int nz, const double* zD, const int* zLay, double* h, double* dh, ucf_stats* stats)
@@ -473,9 +556,8 @@ int ucf_drawdown_batch(ucf_plan* pl, int npts, const double* tD, const double* r
     if (stats) std::memset(stats, 0, sizeof(*stats));
     if (npts == 0) return UCF_OK;
     if (!tD || !rD || !sv || !h || !dh) return fail(UCF_ERR_BAD_ARGUMENT, "NULL array");
-    for (int i = 0; i < npts; i++)
-        if (sv[i] < 1 || sv[i] + pl->P.nacc > pl->D.nj0z)
-            return fail(UCF_ERR_BAD_ARGUMENT, "sv[%d]=%d outside 1..%d", i, sv[i], pl->D.nj0z - pl->P.nacc);
+    int rc = check_sv(pl, npts, sv);
+    if (rc) return rc;
     dev_buf b_t, b_r, b_s, b_h, b_d, b_st;
     const size_t nb = sizeof(double) * (size_t)npts;
     if (b_t.alloc(nb) || b_r.alloc(nb) || b_s.alloc(sizeof(int) * (size_t)npts) || b_h.alloc(nb * nz) ||
@@ -485,12 +567,45 @@ int ucf_drawdown_batch(ucf_plan* pl, int npts, const double* tD, const double* r
     HIP_TRY(hipMemcpy(b_r.p, rD, nb, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(b_s.p, sv, sizeof(int) * (size_t)npts, hipMemcpyHostToDevice));
     HIP_TRY(hipMemset(b_st.p, 0, sizeof(ucf_stats)));
-    int rc = ucf_drawdown_batch_device(pl, npts, (const double*)b_t.p, (const double*)b_r.p, (const int*)b_s.p, nz, zD,
-                                       zLay, (double*)b_h.p, (double*)b_d.p, stats ? (ucf_stats*)b_st.p : nullptr, nullptr);
+    rc = ucf_drawdown_batch_device(pl, npts, (const double*)b_t.p, (const double*)b_r.p, (const int*)b_s.p, nz, zD,
+                                   zLay, (double*)b_h.p, (double*)b_d.p, stats ? (ucf_stats*)b_st.p : nullptr, nullptr);
     if (rc) return rc;
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(h, b_h.p, nb * nz, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(dh, b_d.p, nb * nz, hipMemcpyDeviceToHost));
+    if (stats) HIP_TRY(hipMemcpy(stats, b_st.p, sizeof(ucf_stats), hipMemcpyDeviceToHost));
+    return UCF_OK;
+}
+
+int ucf_drawdown_grid(ucf_plan* pl, int nt, const double* tD, const int* sv, int nr, const double* rD,
+                      int nz, const double* zD, const int* zLay, double* h, double* dh, ucf_stats* stats)
+{
+    if (!pl) return fail(UCF_ERR_BAD_ARGUMENT, "NULL plan");
+    if (nt < 0 || nr < 0) return fail(UCF_ERR_BAD_ARGUMENT, "negative grid size");
+    if (stats) std::memset(stats, 0, sizeof(*stats));
+    if (nt == 0 || nr == 0) return UCF_OK;
+    if (!tD || !rD || !sv || !h || !dh) return fail(UCF_ERR_BAD_ARGUMENT, "NULL array");
+    int rc = check_sv(pl, nt, sv);
+    if (rc) return rc;
+    const int* j0s = pl->P.j0s;
+    const int svmin = j0s[0] < j0s[1] ? j0s[0] : j0s[1], svmax = j0s[0] > j0s[1] ? j0s[0] : j0s[1];
+    for (int i = 0; i < nt; i++)
+        if (sv[i] < svmin || sv[i] > svmax) return fail(UCF_ERR_BAD_ARGUMENT, "sv[%d]=%d outside the plan's split range %d..%d", i, sv[i], svmin, svmax);
+    dev_buf b_t, b_r, b_s, b_h, b_d, b_st;
+    const size_t no = sizeof(double) * (size_t)nt * nr * nz;
+    if (b_t.alloc(sizeof(double) * nt) || b_r.alloc(sizeof(double) * nr) || b_s.alloc(sizeof(int) * nt) || b_h.alloc(no) ||
+        b_d.alloc(no) || b_st.alloc(sizeof(ucf_stats)))
+        return fail(UCF_ERR_NOMEM, "device allocation failed for a %d x %d grid", nt, nr);
+    HIP_TRY(hipMemcpy(b_t.p, tD, sizeof(double) * nt, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(b_r.p, rD, sizeof(double) * nr, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(b_s.p, sv, sizeof(int) * nt, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(b_st.p, 0, sizeof(ucf_stats)));
+    rc = ucf_drawdown_grid_device(pl, nt, (const double*)b_t.p, (const int*)b_s.p, nr, (const double*)b_r.p, nz, zD, zLay,
+                                  (double*)b_h.p, (double*)b_d.p, stats ? (ucf_stats*)b_st.p : nullptr, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(h, b_h.p, no, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(dh, b_d.p, no, hipMemcpyDeviceToHost));
     if (stats) HIP_TRY(hipMemcpy(stats, b_st.p, sizeof(ucf_stats), hipMemcpyDeviceToHost));
     return UCF_OK;
 }

@@ -43,6 +43,10 @@ UCF_DEV void stat_add(long long* ctr, bool pred)
 typedef double2 lds_c;   // one complex per lane per slot
 UCF_DEV cplx lds_ld(const lds_c* base, int slot, int lane) { lds_c v = base[slot * UCF_WAVE + lane]; return cmake(v.x, v.y); }
 UCF_DEV void lds_st(lds_c* base, int slot, int lane, cplx z) { base[slot * UCF_WAVE + lane] = make_double2(z.re, z.im); }
+// scratch columns hold one half-wave (32 lanes) per slot: the per-lane tails (Neville, Wynn) run on
+// one half-wave at a time, which halves their LDS footprint at < 2 % of the point's time
+UCF_DEV cplx scr_ld(const lds_c* base, int slot, int lane) { lds_c v = base[slot * (UCF_WAVE / 2) + (lane & 31)]; return cmake(v.x, v.y); }
+UCF_DEV void scr_st(lds_c* base, int slot, int lane, cplx z) { base[slot * (UCF_WAVE / 2) + (lane & 31)] = make_double2(z.re, z.im); }
 
 // ------------------------------------------------------------------ time.f90:34-80
 UCF_DEV cplx lap_time(const ucf_dev_params& P, cplx p)
@@ -231,6 +235,12 @@ UCF_DEV cplx sample_z(const ucf_dev_params& P, const sample_common& S, int iz)
     return sH;                                                                                  // :525
 }
 
+}  // namespace UCF_NS
+#if UCF_FAST
+#include "ucf_fastpath.h"
+#endif
+namespace UCF_NS {
+
 // ------------------------------------------------------------------ invlap.f90:46-141
 // Wave-cooperative de Hoog: lane i holds f(p_i), i = 0..2M.  Returns f(t) (uniform).
 UCF_DEV double dehoog_wave(cplx f, int M, double alpha, double logtol, double t, double tee, int lane,
@@ -296,8 +306,29 @@ UCF_DEV double dehoog_wave(cplx f, int M, double alpha, double logtol, double t,
 
 // ------------------------------------------------------------- integration.f90:125-189
 // Per-lane Wynn-epsilon on LDS columns.  colA[(i*strideA)][lane] holds series(i+1) on
-// entry (overwritten by the even epsilon columns); colB is scratch (odd columns).
+// entry (overwritten by the even epsilon columns); colB is half-wave scratch (odd columns).
 // status: 0 ok, 1 truncated, 2 sentinel, 3 early exit.
+template <bool CUR_IS_A>
+UCF_DEV bool wynn_column(lds_c* colA, int strideA, lds_c* colB, int count, int lane, cplx* acc)
+{
+    // new(m) = prev(m+1) + 1/(cur(m+1) - cur(m)), m = 1..count; new column overwrites prev storage
+    for (int m = 1; m <= count; m++) {
+        const cplx hi = CUR_IS_A ? lds_ld(colA, m * strideA, lane) : scr_ld(colB, m, lane);
+        const cplx lo = CUR_IS_A ? lds_ld(colA, (m - 1) * strideA, lane) : scr_ld(colB, m - 1, lane);
+        const cplx denom = csub(hi, lo);
+        if (cabs_(denom) > UCF_EPS) {                                                           // :172
+            const cplx pv = CUR_IS_A ? scr_ld(colB, m, lane) : lds_ld(colA, m * strideA, lane);
+            const cplx nw = cadd(pv, rdiv(1.0, denom));                                         // :173
+            if (CUR_IS_A) scr_st(colB, m - 1, lane, nw);
+            else lds_st(colA, (m - 1) * strideA, lane, nw);
+        } else {
+            *acc = hi;                                                                          // :175
+            return true;
+        }
+    }
+    return false;
+}
+
 UCF_DEV cplx wynn_lane(lds_c* colA, int strideA, lds_c* colB, int nin, int lane, int* status)
 {
     int ns = nin;
@@ -317,28 +348,14 @@ UCF_DEV cplx wynn_lane(lds_c* colA, int strideA, lds_c* colB, int nin, int lane,
         *status = 2;
         return cmake((double)(-999999.9f), 0.0);                                                // :148
     }
-    for (int m = 0; m < ns; m++) lds_st(colB, m, lane, cmake(0.0, 0.0));                        // :166
+    for (int m = 0; m < ns; m++) scr_st(colB, m, lane, cmake(0.0, 0.0));                        // :166
     cplx acc = cmake(0.0, 0.0);
     bool done = false;
     for (int j = 0; j <= ns - 2 && !done; j++) {                                                // :169-181
-        lds_c* cur = (j & 1) ? colB : colA;
-        lds_c* prv = (j & 1) ? colA : colB;
-        const int scur = (j & 1) ? 1 : strideA;
-        const int sprv = (j & 1) ? strideA : 1;
-        for (int m = 1; m <= ns - (j + 1); m++) {
-            cplx hi = lds_ld(cur, m * scur, lane);
-            cplx lo = lds_ld(cur, (m - 1) * scur, lane);
-            cplx denom = csub(hi, lo);
-            if (cabs_(denom) > UCF_EPS) {
-                cplx nw = cadd(lds_ld(prv, m * sprv, lane), rdiv(1.0, denom));
-                lds_st(prv, (m - 1) * sprv, lane, nw);
-            } else {
-                acc = hi;
-                stat = 3;
-                done = true;
-                break;
-            }
-        }
+        const int count = ns - (j + 1);
+        done = (j & 1) ? wynn_column<false>(colA, strideA, colB, count, lane, &acc)
+                       : wynn_column<true>(colA, strideA, colB, count, lane, &acc);
+        if (done) stat = 3;
     }
     if (!done) acc = lds_ld(colA, 1 * strideA, lane);   // eps(2,ns-2) [ns even] or eps(2,ns-3) [ns odd]: both even columns
     *status = stat;
@@ -347,28 +364,28 @@ UCF_DEV cplx wynn_lane(lds_c* colA, int strideA, lds_c* colB, int nin, int lane,
 
 // ------------------------------------------------------------- integration.f90:192-237
 // Per-lane Neville extrapolation to x = 0.  colC[(i*strideC)][lane] holds y(i+1) (destroyed),
-// colD is scratch.  x is wave-uniform.
+// colD is half-wave scratch.  x is wave-uniform.
 UCF_DEV cplx extrap_lane(lds_c* colC, int strideC, lds_c* colD, const double* x, int n, int lane)
 {
     int ns = 1;
     for (int i = 2; i <= n; i++) if (x[i - 1] < x[ns - 1]) ns = i;                              // minloc
-    for (int i = 0; i < n; i++) lds_st(colD, i, lane, lds_ld(colC, i * strideC, lane));
+    for (int i = 0; i < n; i++) scr_st(colD, i, lane, lds_ld(colC, i * strideC, lane));
     cplx y = lds_ld(colC, (ns - 1) * strideC, lane);
     ns = ns - 1;
     for (int m = 1; m <= n - 1; m++) {
         for (int i = 1; i <= n - m; i++) {
             const double dx = x[i - 1] - x[i + m - 1];
             cplx ci = lds_ld(colC, i * strideC, lane);
-            cplx di = lds_ld(colD, i - 1, lane);
+            cplx di = scr_ld(colD, i - 1, lane);
             cplx den = cdiv(csub(ci, di), cmake(dx, 0.0));                                      // :227 (complex/complex)
-            lds_st(colD, i - 1, lane, rscale(x[i + m - 1], den));
+            scr_st(colD, i - 1, lane, rscale(x[i + m - 1], den));
             lds_st(colC, (i - 1) * strideC, lane, rscale(x[i - 1], den));
         }
         cplx dy;
         if (2 * ns < n - m) {
             dy = lds_ld(colC, ns * strideC, lane);
         } else {
-            dy = lds_ld(colD, ns - 1, lane);
+            dy = scr_ld(colD, ns - 1, lane);
             ns = ns - 1;
         }
         y = cadd(y, dy);
@@ -376,77 +393,127 @@ UCF_DEV cplx extrap_lane(lds_c* colC, int strideC, lds_c* colD, const double* x,
     return y;
 }
 
+// ------------------------------------------------------------------ abscissa tables
+// Everything about an abscissa that does not depend on the Laplace sample: a_n and
+// a_n*J0(a_n*rD) (laplace_hankel_solutions.f90:118).  It depends only on (rD, sv), so a sweep
+// computes it once per radius (and split index) instead of once per lane, time and abscissa:
+// row-major table tab[row][n] = (a, a*J0(a*rD)), n < N tanh-sinh (integration.f90:62 with this
+// row's own arg), n >= N Gauss-Lobatto nodes between J0 zeros (driver.f90:189-193).
+#if !UCF_FAST
+__global__ void __launch_bounds__(256)
+abscissa_kernel(const ucf_dev_params P, int nrows, int per_point, int nsv, int svmin,
+                const double* __restrict__ rDv, const int* __restrict__ svv, double2* __restrict__ tab)
+{
+    const int nabs = P.N + P.nacc * P.ngl;
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long long)nrows * nabs) return;
+    const int row = (int)(gid / nabs), n = (int)(gid % nabs);
+    double rD;
+    int sv;
+    if (per_point) { rD = rDv[row]; sv = svv[row]; }
+    else { rD = rDv[row / nsv]; sv = svmin + row % nsv; }
+    double a;
+    if (n < P.N) {
+        const double arg = P.j0z[sv - 1] / rD;                                                  // driver.f90:120
+        a = (P.ts_x[n] * arg) / 2.0;                                                            // integration.f90:62
+    } else {
+        const int jj = (n - P.N) / P.ngl, m = (n - P.N) % P.ngl;
+        const double lob = P.j0z[sv + jj - 1] / rD;                                             // driver.f90:188-190
+        const double hib = P.j0z[sv + jj] / rD;
+        const double width = hib - lob;
+        a = (width * P.gl_x[m] + (hib + lob)) / 2.0;                                            // :193
+    }
+    tab[gid] = make_double2(a, a * j0(a * rD));
+}
+#endif
+
 // ------------------------------------------------------------------ the point kernel
 // driver.f90:100-232 for one (t,r) point per wavefront (single-point-run semantics,
 // SURVEY.md quirks Q1 and Q5).
 // LDS per wave (slots of 64 complex):  [R*nz] level sums | [nacc*nz] interval areas |
-// [max(nacc,R)] scratch | FAMILY 4: [2*order] Thomas sweep.
+// [max(nacc,R)] x 32 lanes scratch (Richardson / Wynn run on one half-wave at a time) |
+// FAMILY 4: [2*order] Thomas sweep.
 template <int FAMILY>
-__global__ void __launch_bounds__(UCF_WAVE)
-point_kernel(const ucf_dev_params P, int npts, const double* __restrict__ tDv, const double* __restrict__ rDv,
-             const int* __restrict__ svv, double* __restrict__ hout, double* __restrict__ dhout, ucf_stats* st)
+__global__ void __launch_bounds__(UCF_WAVE, 2)
+point_kernel(const ucf_dev_params P, int npts, int per_point, int nr, int nsv, int svmin,
+             const double* __restrict__ tDv, const double* __restrict__ rDv, const int* __restrict__ svv,
+             const double2* __restrict__ tab, double* __restrict__ hout, double* __restrict__ dhout, ucf_stats* st)
 {
     extern __shared__ lds_c lds[];
     const int lane = threadIdx.x;
     const int nz = P.nz, R = P.R, nacc = P.nacc, N = P.N, ngl = P.ngl;
-    lds_c* accTS = lds;                          // [R][nz]
-    lds_c* accGL = lds + (size_t)R * nz * UCF_WAVE;        // [nacc][nz]
-    lds_c* scr = accGL + (size_t)nacc * nz * UCF_WAVE;     // [max(nacc,R)]
-    lds_c* fdbuf = scr + (size_t)(nacc > R ? nacc : R) * UCF_WAVE;
+    const int nabs = N + nacc * ngl;
+    lds_c* accTS = lds;                                     // [R][nz]
+    lds_c* accGL = lds + (size_t)R * nz * UCF_WAVE;         // [nacc][nz]
+    lds_c* scr = accGL + (size_t)nacc * nz * UCF_WAVE;      // [max(nacc,R)] half-wave slots
+    lds_c* fdbuf = scr + (size_t)(nacc > R ? nacc : R) * (UCF_WAVE / 2);
 
     bool need_lay1 = false;
     for (int z = 0; z < nz; z++) need_lay1 |= (P.zLay[z] == 1);
 
     for (int pt = blockIdx.x; pt < npts; pt += gridDim.x) {
-        const double tD = tDv[pt], rD = rDv[pt];
-        const int sv = svv[pt];
+        const int it = per_point ? pt : pt / nr;
+        const int ir = per_point ? pt : pt % nr;
+        const double tD = tDv[it], rD = rDv[ir];
+        const int sv = svv[it];
+        const double2* __restrict__ row = tab + (size_t)(per_point ? pt : (ir * nsv + (sv - svmin))) * nabs;
         const double tee = 2.0 * tD;                                                            // driver.f90:106,217
         const double sigma = P.alpha - P.logtol / (2.0 * tee);                                  // invlap.f90:165
         const cplx p = cmake(sigma, UCF_PI * lane / tee);                                       // invlap.f90:168
         const cplx lt = lap_time(P, p);
         const double arg = P.j0z[sv - 1] / rD;                                                  // driver.f90:120
+#if UCF_FAST
+        const lane_consts LC = make_lane_consts(P, p, lt);
+#endif
 
         for (int s = 0; s < (R + nacc) * nz; s++) lds_st(lds, s, lane, cmake(0.0, 0.0));
 
-        // ---- finite part: tanh-sinh on [0, arg], all Richardson levels from one pass (:129-157)
-        for (int n = 1; n <= N; n++) {
-            const double a = (P.ts_x[n - 1] * arg) / 2.0;                                       // integration.f90:62
-            const double aj = a * j0(a * rD);                                                   // lhs.f90:118
+        // one pass over all abscissae: n < N tanh-sinh on [0,arg] feeding every Richardson level
+        // (driver.f90:129-157); n >= N Gauss-Lobatto between successive J0 zeros (:187-203)
+        for (int n = 0; n < nabs; n++) {
+            const double2 aa = row[n];
+            const double a = aa.x, aj = aa.y;
+            const bool ts = n < N;
+            const int g = ts ? 0 : (n - N);
+            const int jj = g / ngl, m = g - jj * ngl;
+            // val = a*J0(a rD) * f(a,p,z) * lapTime(p)  (lhs.f90:118), accumulated into the level sums /
+            // the current interval's area
+            auto accumulate = [&](int z, cplx f) {
+                const cplx val = cmul(rscale(aj, f), lt);
+                if (ts) {
+                    const int n1 = n + 1;
+                    for (int j = 1; j <= R; j++) {
+                        const int sh = R - j;
+                        if ((n1 & ((1 << sh) - 1)) == 0) {                                      // driver.f90:150
+                            const double w = P.ts_w[(size_t)(j - 1) * N + ((n1 >> sh) - 1)];
+                            const int slot = (j - 1) * nz + z;
+                            lds_st(accTS, slot, lane, cadd(lds_ld(accTS, slot, lane), rscale(w, val)));
+                        }
+                    }
+                } else {
+                    const int slot = jj * nz + z;
+                    cplx acc = cadd(lds_ld(accGL, slot, lane), cscale(val, P.gl_w[m]));         // :201-202
+                    if (m == ngl - 1) {
+                        const double lob = P.j0z[sv + jj - 1] / rD;
+                        const double hib = P.j0z[sv + jj] / rD;
+                        acc = rscale((hib - lob) / 2.0, acc);
+                    }
+                    lds_st(accGL, slot, lane, acc);
+                }
+            };
+#if UCF_FAST
+            if (FAMILY == 1 || FAMILY == 2) {
+                fast_common F;
+                const bool ok = fast_prepare<FAMILY>(P, LC, a, need_lay1, F);
+                if (__all(ok)) {
+                    for (int z = 0; z < nz; z++) accumulate(z, fast_sample_z<FAMILY>(P, F, z));
+                    continue;
+                }
+            }
+#endif
             sample_common S;
             sample_prepare<FAMILY>(P, a, p, need_lay1, S, fdbuf, lane);
-            for (int z = 0; z < nz; z++) {
-                const cplx val = cmul(rscale(aj, sample_z<FAMILY>(P, S, z)), lt);               // lhs.f90:118
-                for (int j = 1; j <= R; j++) {
-                    const int sh = R - j;
-                    if ((n & ((1 << sh) - 1)) == 0) {                                           // driver.f90:150
-                        const double w = P.ts_w[(size_t)(j - 1) * N + ((n >> sh) - 1)];
-                        const int slot = (j - 1) * nz + z;
-                        lds_st(accTS, slot, lane, cadd(lds_ld(accTS, slot, lane), rscale(w, val)));
-                    }
-                }
-            }
-        }
-        // ---- infinite part: Gauss-Lobatto between successive J0 zeros (:187-203)
-        for (int jj = 1; jj <= nacc; jj++) {
-            const double lob = P.j0z[sv + jj - 2] / rD;
-            const double hib = P.j0z[sv + jj - 1] / rD;
-            const double width = hib - lob;
-            for (int m = 0; m < ngl; m++) {
-                const double a = (width * P.gl_x[m] + (hib + lob)) / 2.0;                       // :193
-                const double aj = a * j0(a * rD);
-                const double w = P.gl_w[m];
-                sample_common S;
-                sample_prepare<FAMILY>(P, a, p, need_lay1, S, fdbuf, lane);
-                for (int z = 0; z < nz; z++) {
-                    const cplx val = cmul(rscale(aj, sample_z<FAMILY>(P, S, z)), lt);
-                    const int slot = (jj - 1) * nz + z;
-                    lds_st(accGL, slot, lane, cadd(lds_ld(accGL, slot, lane), cscale(val, w)));  // :201-202
-                }
-            }
-            for (int z = 0; z < nz; z++) {
-                const int slot = (jj - 1) * nz + z;
-                lds_st(accGL, slot, lane, rscale(width / 2.0, lds_ld(accGL, slot, lane)));
-            }
+            for (int z = 0; z < nz; z++) accumulate(z, sample_z<FAMILY>(P, S, z));
         }
         // ---- per depth: Richardson, Wynn-epsilon, de Hoog (:159-230)
         for (int z = 0; z < nz; z++) {
@@ -454,14 +521,17 @@ point_kernel(const ucf_dev_params P, int npts, const double* __restrict__ tDv, c
                 const int slot = j * nz + z;
                 lds_st(accTS, slot, lane, rscale(arg / 2.0, lds_ld(accTS, slot, lane)));        // :135,154
             }
-            cplx finint;
-            if (R > 1) finint = extrap_lane(accTS + (size_t)z * UCF_WAVE, nz, scr, P.hv, R, lane);
-            else finint = lds_ld(accTS, z, lane);
             bool any = false;
             for (int jj = 0; jj < nacc; jj++) any |= (cabs_(lds_ld(accGL, jj * nz + z, lane)) > 0.0);   // :209
+            cplx finint = lds_ld(accTS, z, lane);
             cplx infint = cmake(0.0, 0.0);
             int wst = 0;
-            if (any) infint = wynn_lane(accGL + (size_t)z * UCF_WAVE, nz, scr, nacc, lane, &wst);
+            for (int half = 0; half < 2; half++) {
+                if ((lane >> 5) == half) {
+                    if (R > 1) finint = extrap_lane(accTS + (size_t)z * UCF_WAVE, nz, scr, P.hv, R, lane);
+                    if (any) infint = wynn_lane(accGL + (size_t)z * UCF_WAVE, nz, scr, nacc, lane, &wst);
+                }
+            }
             if (st) {
                 const bool live = lane < P.np;
                 stat_add(&st->wynn_all_zero, live && !any);
@@ -499,9 +569,23 @@ samples_kernel(const ucf_dev_params P, int n_a, const double* __restrict__ av, d
     const cplx lt = lap_time(P, p);
     const double aj = a * j0(a * rD);
     sample_common S;
-    sample_prepare<FAMILY>(P, a, p, need_lay1, S, lds, lane);
+    bool fast = false;
+#if UCF_FAST
+    fast_common F;
+    if (FAMILY == 1 || FAMILY == 2) {
+        const lane_consts LC = make_lane_consts(P, p, lt);
+        fast = __all(fast_prepare<FAMILY>(P, LC, a, need_lay1, F));
+    }
+#endif
+    if (!fast) sample_prepare<FAMILY>(P, a, p, need_lay1, S, lds, lane);
     for (int z = 0; z < P.nz; z++) {
-        const cplx val = cmul(rscale(aj, sample_z<FAMILY>(P, S, z)), lt);
+        cplx f;
+#if UCF_FAST
+        if (fast) f = fast_sample_z<(FAMILY == 1 || FAMILY == 2) ? FAMILY : 1>(P, F, z);
+        else
+#endif
+            f = sample_z<FAMILY>(P, S, z);
+        const cplx val = cmul(rscale(aj, f), lt);
         if (live) {
             const size_t o = (((size_t)ia * P.nz + z) * P.np + lane) * 2;
             fp[o] = val.re;
@@ -537,7 +621,9 @@ wynn_kernel(int n, int nterms, const double* __restrict__ series, double* __rest
     for (int k = 0; k < nterms; k++)
         lds_st(colA, k, lane, cmake(series[((size_t)ii * nterms + k) * 2], series[((size_t)ii * nterms + k) * 2 + 1]));
     int stt = 0;
-    cplx r = wynn_lane(colA, 1, colB, nterms, lane, &stt);
+    cplx r = cmake(0.0, 0.0);
+    for (int half = 0; half < 2; half++)
+        if ((lane >> 5) == half) r = wynn_lane(colA, 1, colB, nterms, lane, &stt);
     if (i < n) {
         acc[2 * i] = r.re;
         acc[2 * i + 1] = r.im;
@@ -556,7 +642,9 @@ extrap_kernel(int n, int R, const double* __restrict__ x, const double* __restri
     const int ii = i < n ? i : n - 1;
     for (int k = 0; k < R; k++)
         lds_st(colC, k, lane, cmake(y[((size_t)ii * R + k) * 2], y[((size_t)ii * R + k) * 2 + 1]));
-    cplx r = extrap_lane(colC, 1, colD, x, R, lane);
+    cplx r = cmake(0.0, 0.0);
+    for (int half = 0; half < 2; half++)
+        if ((lane >> 5) == half) r = extrap_lane(colC, 1, colD, x, R, lane);
     if (i < n) {
         out[2 * i] = r.re;
         out[2 * i + 1] = r.im;
@@ -578,13 +666,27 @@ static inline int family_of(const ucf_dev_params& dp)
 
 static inline size_t point_lds_bytes(const ucf_dev_params& dp)
 {
-    size_t slots = (size_t)(dp.R + dp.nacc) * dp.nz + (size_t)(dp.nacc > dp.R ? dp.nacc : dp.R);
-    if (family_of(dp) == 4) slots += 2 * (size_t)dp.order;
-    return slots * UCF_WAVE * sizeof(lds_c);
+    size_t bytes = ((size_t)(dp.R + dp.nacc) * dp.nz * UCF_WAVE + (size_t)(dp.nacc > dp.R ? dp.nacc : dp.R) * (UCF_WAVE / 2)) * sizeof(lds_c);
+    if (family_of(dp) == 4) bytes += 2 * (size_t)dp.order * UCF_WAVE * sizeof(lds_c);
+    return bytes;
 }
 
-int launch_points(const ucf_dev_params& dp, int npts, const double* d_tD, const double* d_rD, const int* d_sv,
-                  double* d_h, double* d_dh, ucf_stats* d_stats, void* stream)
+#if !UCF_FAST
+int launch_abscissae(const ucf_dev_params& dp, int nrows, int per_point, int nsv, int svmin, const double* d_rD,
+                     const int* d_sv, double* d_tab, void* stream)
+{
+    const long long total = (long long)nrows * (dp.N + dp.nacc * dp.ngl);
+    const int threads = 256;
+    const long long blocks = (total + threads - 1) / threads;
+    hipLaunchKernelGGL(abscissa_kernel, dim3((unsigned)blocks), dim3(threads), 0, (hipStream_t)stream, dp, nrows, per_point,
+                       nsv, svmin, d_rD, d_sv, (double2*)d_tab);
+    return hipGetLastError() == hipSuccess ? UCF_OK : UCF_ERR_HIP;
+}
+#endif
+
+int launch_points(const ucf_dev_params& dp, int npts, int per_point, int nr, int nsv, int svmin, const double* d_tD,
+                  const double* d_rD, const int* d_sv, const double* d_tab, double* d_h, double* d_dh,
+                  ucf_stats* d_stats, void* stream)
 {
     const int fam = family_of(dp);
     if (fam < 0) return UCF_ERR_UNSUPPORTED;
@@ -596,7 +698,8 @@ int launch_points(const ucf_dev_params& dp, int npts, const double* d_tD, const 
     do {                                                                                                       \
         if (lds > 64 * 1024)                                                                                   \
             (void)hipFuncSetAttribute((const void*)point_kernel<F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL(point_kernel<F>, grid, block, lds, s, dp, npts, d_tD, d_rD, d_sv, d_h, d_dh, d_stats); \
+        hipLaunchKernelGGL(point_kernel<F>, grid, block, lds, s, dp, npts, per_point, nr, nsv, svmin, d_tD, d_rD, d_sv,   \
+                           (const double2*)d_tab, d_h, d_dh, d_stats);                                         \
     } while (0)
     switch (fam) {
     case 0: UCF_LAUNCH(0); break;
@@ -644,14 +747,14 @@ int launch_dehoog(int n, int M, double alpha, double logtol, const double* d_t, 
 }
 int launch_wynn(int n, int nterms, const double* d_series, double* d_acc, int* d_status, void* stream)
 {
-    const size_t lds = 2 * (size_t)nterms * UCF_WAVE * sizeof(lds_c);
+    const size_t lds = ((size_t)nterms * UCF_WAVE + (size_t)nterms * (UCF_WAVE / 2)) * sizeof(lds_c);
     hipLaunchKernelGGL(wynn_kernel, dim3((n + UCF_WAVE - 1) / UCF_WAVE), dim3(UCF_WAVE), lds, (hipStream_t)stream, n,
                        nterms, d_series, d_acc, d_status);
     return hipGetLastError() == hipSuccess ? UCF_OK : UCF_ERR_HIP;
 }
 int launch_extrap(int n, int R, const double* d_x, const double* d_y, double* d_out, void* stream)
 {
-    const size_t lds = 2 * (size_t)R * UCF_WAVE * sizeof(lds_c);
+    const size_t lds = ((size_t)R * UCF_WAVE + (size_t)R * (UCF_WAVE / 2)) * sizeof(lds_c);
     hipLaunchKernelGGL(extrap_kernel, dim3((n + UCF_WAVE - 1) / UCF_WAVE), dim3(UCF_WAVE), lds, (hipStream_t)stream, n,
                        R, d_x, d_y, d_out);
     return hipGetLastError() == hipSuccess ? UCF_OK : UCF_ERR_HIP;

@@ -1,0 +1,232 @@
+// ucf_fastpath.h -- "fast" flavour of the Hantush-based sample evaluators (families 1, 2, 4:
+// Hantush, Moench / Malama / Neuman water-table closure, Mishra-Neuman FD).
+//
+// Same formulas as laplace_hankel_solutions.f90:64-93,133-202 (cited per line below), evaluated
+// with the minimum of work a wave needs:
+//   * every cosh/sinh/exp of eta*c comes from ONE primitive per distinct real factor c:
+//     E = exp(|Re|), 1/E by Newton reciprocal, sincos(Im) by a two-stage Cody-Waite reduction
+//     and the fdlibm kernels; cosh, sinh and exp(-.) of that argument are 2-4 multiplies away;
+//   * divisions by per-lane constants (p, kappa, bD, Moench sum) are reciprocals hoisted out of
+//     the abscissa loop; sinh(eta) and the closure denominator are inverted once per sample;
+//   * exact zeros are folded at plan level: a fully penetrating well (d = 0, l = b) has
+//     sinh(eta*dD) = sinh(eta*lD1) = 0 and cosh(eta*(dD1-1)) = 1 identically.
+// The fast evaluation is only used while Re(eta)*cmax <= 700, i.e. while no cosh/sinh or product
+// of two of them can overflow; beyond that the generic evaluator (which reproduces the
+// reference's Inf/NaN behaviour, needed by the in-band rules) takes over for the whole wave.
+#pragma once
+
+namespace UCF_NS {
+
+struct fprim {
+    double ch, sh, ei, sn, cs;    // cosh(x), sinh(x), exp(-|x|), sin(y), cos(y)
+};
+
+// exp(x), 0 <= x <= 709.  k = rint(x/ln2), r = x - k ln2 (two-part), degree-13 Taylor in r
+// (|r| <= 0.3466: truncation 4e-18), scaled by 2^k.
+UCF_DEV double exp_pos(double x)
+{
+    const double k = __builtin_rint(x * 1.4426950408889634074);
+    double r = __builtin_fma(-k, 6.93147180369123816490e-01, x);
+    r = __builtin_fma(-k, 1.90821492927058770002e-10, r);
+    double q = 1.0 / 6227020800.0;
+    q = __builtin_fma(q, r, 1.0 / 479001600.0);
+    q = __builtin_fma(q, r, 1.0 / 39916800.0);
+    q = __builtin_fma(q, r, 1.0 / 3628800.0);
+    q = __builtin_fma(q, r, 1.0 / 362880.0);
+    q = __builtin_fma(q, r, 1.0 / 40320.0);
+    q = __builtin_fma(q, r, 1.0 / 5040.0);
+    q = __builtin_fma(q, r, 1.0 / 720.0);
+    q = __builtin_fma(q, r, 1.0 / 120.0);
+    q = __builtin_fma(q, r, 1.0 / 24.0);
+    q = __builtin_fma(q, r, 1.0 / 6.0);
+    q = __builtin_fma(q, r, 0.5);
+    q = __builtin_fma(q, r, 1.0);
+    q = __builtin_fma(q, r, 1.0);
+    return ldexp(q, (int)k);
+}
+
+UCF_DEV fprim prim(double x, double y)
+{
+    fprim f;
+    const double ax = fabs(x);
+    const double e = exp_pos(ax);
+    const double ei = fast_rcp(e);
+    f.ei = ei;
+    f.ch = 0.5 * (e + ei);
+    double s;
+    if (ax < 0.35) {
+        const double x2 = ax * ax;
+        double pl = 1.0 / 6227020800.0;
+        pl = __builtin_fma(pl, x2, 1.0 / 39916800.0);
+        pl = __builtin_fma(pl, x2, 1.0 / 362880.0);
+        pl = __builtin_fma(pl, x2, 1.0 / 5040.0);
+        pl = __builtin_fma(pl, x2, 1.0 / 120.0);
+        pl = __builtin_fma(pl, x2, 1.0 / 6.0);
+        s = __builtin_fma(ax * x2, pl, ax);
+    } else {
+        s = 0.5 * (e - ei);
+    }
+    f.sh = copysign(s, x);
+    sincos_(y, &f.sn, &f.cs);
+    return f;
+}
+UCF_DEV cplx pcosh(const fprim& f) { return cmake(f.ch * f.cs, f.sh * f.sn); }
+UCF_DEV cplx psinh(const fprim& f) { return cmake(f.sh * f.cs, f.ch * f.sn); }
+// exp(-(x+iy)) for x >= 0
+UCF_DEV cplx pexpneg(const fprim& f) { return cmake(f.ei * f.cs, -(f.ei * f.sn)); }
+
+// 1/z without scaling: |z| in [1e-150, 1e150]
+UCF_DEV cplx cinv_plain(cplx z)
+{
+    const double r = fast_rcp(z.re * z.re + z.im * z.im);
+    return cmake(z.re * r, -(z.im * r));
+}
+// 1/z with the exponent scaling of __divdc3 (|z| may be up to e^700)
+UCF_DEV cplx cinv_scaled(cplx z)
+{
+    const double m = fmax(fabs(z.re), fabs(z.im));
+    const int il = __builtin_amdgcn_frexp_exp(m) - 1;
+    const double c = ldexp(z.re, -il), d = ldexp(z.im, -il);
+    const double r = fast_rcp(c * c + d * d);
+    return cmake(ldexp(c * r, -il), ldexp(-(d * r), -il));
+}
+
+struct lane_consts {     // per lane, constant over the abscissa loop of one point
+    cplx p, lt, xifac;   // xifac = alphaD/p [* MoenchM / sum_m 1/(1+p/gamma_m)]   (:70,72-75)
+};
+
+UCF_DEV lane_consts make_lane_consts(const ucf_dev_params& P, cplx p, cplx lt)
+{
+    lane_consts L;
+    L.p = p;
+    L.lt = lt;
+    cplx xf = rscale(P.alphaD, cinv_plain(p));
+    if (P.model == 3) {
+        cplx sum = cmake(0.0, 0.0);
+        for (int j = 0; j < P.MoenchM; j++) sum = cadd(sum, cinv_plain(radd(1.0, cscale(p, P.MoenchInvGamma[j]))));
+        xf = cmul(cscale(xf, (double)P.MoenchM), cinv_plain(sum));
+    }
+    L.xifac = xf;
+    return L;
+}
+
+struct fast_common {
+    cplx th, eta, ff1, ff2, inv_she, she, che, top, g3, inv_den, ex1;   // ex1 = exp(-eta)
+    bool small_eta;
+};
+
+// z-independent part.  Returns false (for this lane) if the fast evaluation is not applicable.
+template <int FAMILY>
+UCF_DEV bool fast_prepare(const ucf_dev_params& P, const lane_consts& L, double a, bool need_lay1, fast_common& S)
+{
+    const double a2 = a * a;
+    const cplx q = caddr(L.p, a2);
+    {
+        const double r = fast_rcp(q.re * q.re + q.im * q.im);
+        S.th = cmake(2.0 * q.re * r, -(2.0 * q.im * r));                                        // :122-131
+    }
+    {   // eta = sqrt(q/kappa), Re q > 0                                                         (:69,172)
+        const double qr = q.re * P.inv_kappa, qi = q.im * P.inv_kappa;
+        const double d = sqrt(qr * qr + qi * qi);
+        const double r = sqrt(0.5 * (d + qr));
+        S.eta = cmake(r, 0.5 * qi * fast_rcp(r));
+    }
+    if (!(S.eta.re <= P.fast_eta_max) || !(q.re > 0.0)) return false;
+    const bool hantush = !(FAMILY == 2 && P.model == 4);
+    const fprim p1 = prim(S.eta.re, S.eta.im);
+    S.che = pcosh(p1);
+    S.she = psinh(p1);
+    S.ex1 = pexpneg(p1);
+    if (hantush) {
+        const bool z1 = P.fold_dD != 0, z2 = P.fold_lD1 != 0;
+        fprim pd;
+        if (!z1) { pd = prim(S.eta.re * P.dD, S.eta.im * P.dD); S.ff1 = psinh(pd); }           // :176
+        else S.ff1 = cmake(0.0, 0.0);
+        fprim pl;
+        if (!z2) { pl = prim(S.eta.re * P.lD1, S.eta.im * P.lD1); S.ff2 = psinh(pl); }         // :177
+        else S.ff2 = cmake(0.0, 0.0);
+        if (!(z1 && z2) || need_lay1) S.inv_she = cinv_scaled(S.she);
+        if (need_lay1) {                                                                        // :183-184
+            const cplx exl = z2 ? cmake(1.0, 0.0) : pexpneg(pl);
+            S.g3 = csub(exl, cmul(cadd(S.ff1, cmul(S.ex1, S.ff2)), S.inv_she));
+        }
+        if (FAMILY != 1) {
+            // water-table value: hantush at zD = 1 (layer 3): g1 - g2                          (:81,162-170,196)
+            cplx g1;
+            if (z1) g1 = cmake(1.0, 0.0);
+            else if (P.share_g1top) g1 = pcosh(pd);
+            else { const double c = P.dD1 - 1.0; g1 = pcosh(prim(S.eta.re * c, S.eta.im * c)); }
+            cplx udp = g1;
+            if (!(z1 && z2)) udp = csub(g1, cmul(cadd(cmul(S.ff1, S.che), S.ff2), S.inv_she));
+            S.top = cscale(cmul(udp, S.th), P.inv_bD);                                          // :200
+        }
+    } else {
+        S.top = S.th;                                                                           // :78-79
+    }
+    if (FAMILY == 2) {
+        const cplx xi = cmul(S.eta, L.xifac);                                                   // :70-75
+        S.small_eta = S.eta.re < P.maxexp;                                                      // :84
+        cplx one_bex = cmake(1.0, 0.0);
+        if (P.beta != 0.0) one_bex = radd(1.0, cmul(rscale(P.beta, S.eta), xi));
+        if (S.small_eta) S.inv_den = cinv_scaled(cadd(cmul(one_bex, S.che), cmul(xi, S.she)));  // :86-87
+        else S.inv_den = cinv_scaled(cadd(one_bex, xi));                                        // :90-91
+    }
+    return true;
+}
+
+// Hantush factor at depth zD (:133-202); chz = cosh(eta*zD) is returned for the closure
+template <int FAMILY>
+UCF_DEV cplx fast_hantush_z(const ucf_dev_params& P, const fast_common& S, double zD, int lay, cplx* chz_out,
+                            cplx* exz_out)
+{
+    const bool z1 = P.fold_dD != 0, z2 = P.fold_lD1 != 0;
+    const bool need_chz = (lay == 1) || !z1 || FAMILY == 2 || FAMILY == 4;
+    cplx chz = cmake(1.0, 0.0);
+    if (need_chz) chz = pcosh(prim(S.eta.re * zD, S.eta.im * zD));
+    *chz_out = chz;
+    cplx udp;
+    if (lay == 1) {
+        udp = cmul(S.g3, chz);                                                                  // :188
+    } else {
+        cplx g2 = cmake(0.0, 0.0);
+        const bool need_1z = !z2 || (FAMILY == 2 && !S.small_eta);
+        fprim p1z;
+        if (need_1z) { const double c = 1.0 - zD; p1z = prim(S.eta.re * c, S.eta.im * c); }
+        if (FAMILY == 2 && !S.small_eta) *exz_out = pexpneg(p1z);                               // exp(eta*(zD-1))
+        if (!(z1 && z2)) {
+            cplx num = cmake(0.0, 0.0);
+            if (!z1) num = cmul(S.ff1, chz);
+            if (!z2) num = cadd(num, cmul(S.ff2, pcosh(p1z)));
+            g2 = cmul(num, S.inv_she);                                                          // :179-180
+        }
+        if (lay == 2) {
+            udp = rsub(1.0, g2);                                                                // :192
+        } else {
+            const double c = P.dD1 - zD;
+            udp = csub(pcosh(prim(S.eta.re * c, S.eta.im * c)), g2);                            // :175,196
+        }
+    }
+    return cscale(cmul(udp, S.th), P.inv_bD);                                                   // :200
+}
+
+template <int FAMILY>
+UCF_DEV cplx fast_sample_z(const ucf_dev_params& P, const fast_common& S, int iz)
+{
+    const double zD = P.zD[iz];
+    const int lay = P.zLay[iz];
+    cplx chz, exz = cmake(0.0, 0.0);
+    if (FAMILY == 1) return fast_hantush_z<1>(P, S, zD, lay, &chz, &exz);
+    cplx u;
+    if (P.model == 4) {
+        u = S.th;
+        if (S.small_eta) chz = pcosh(prim(S.eta.re * zD, S.eta.im * zD));
+        else { const double c = 1.0 - zD; exz = pexpneg(prim(S.eta.re * c, S.eta.im * c)); }
+    } else {
+        u = fast_hantush_z<2>(P, S, zD, lay, &chz, &exz);
+        if (!S.small_eta && lay == 1) { const double c = 1.0 - zD; exz = pexpneg(prim(S.eta.re * c, S.eta.im * c)); }
+    }
+    if (S.small_eta) return csub(u, cmul(cmul(S.top, chz), S.inv_den));                         // :85-87
+    return csub(u, cmul(cmul(S.top, exz), S.inv_den));                                          // :89-91
+}
+
+}  // namespace UCF_NS

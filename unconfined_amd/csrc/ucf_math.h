@@ -75,6 +75,17 @@ __device__ __noinline__ static cplx cdiv_recover(double a, double b, double c, d
     return z;
 }
 
+#if UCF_FAST
+// 1/x to < 1 ulp: hardware estimate (v_rcp_f64) + two Newton steps (fast flavour only)
+UCF_DEV double fast_rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    return r;
+}
+#endif
+
 // compiler-rt __divdc3
 UCF_DEV cplx cdiv(cplx x, cplx y)
 {
@@ -90,7 +101,7 @@ UCF_DEV cplx cdiv(cplx x, cplx y)
     const double denom = c * c + d * d;
     cplx z;
 #if UCF_FAST
-    const double rden = 1.0 / denom;
+    const double rden = fast_rcp(denom);
     z.re = ldexp((a * c + b * d) * rden, -il);
     z.im = ldexp((b * c - a * d) * rden, -il);
 #else
@@ -117,15 +128,65 @@ UCF_DEV bool c_is_finite(cplx z)
 #define UCF_DBL_MIN 2.2250738585072014e-308
 #define UCF_DBL_MAX 1.7976931348623157e308
 
+#if UCF_FAST
+// sin and cos together, |y| < 2^20*pi/2: argument reduction of fdlibm's __ieee754_rem_pio2
+// (medium range, always carried to the second stage: 118 bits of pi/2) + the fdlibm/msun kernels
+// __kernel_sin / __kernel_cos on the reduced (head, tail).  < 1 ulp.  Larger arguments go to libm.
+__device__ __noinline__ static double2 sincos_huge_(double y) { double s, c; sincos(y, &s, &c); return make_double2(s, c); }
+
+UCF_DEV void sincos_(double x, double* sn, double* cs)
+{
+    if (__builtin_expect(!(fabs(x) < 1.0e6), 0)) {     // also NaN/Inf
+        const double2 sc = sincos_huge_(x);
+        *sn = sc.x;
+        *cs = sc.y;
+        return;
+    }
+    const double fn = __builtin_rint(x * 6.36619772367581382433e-01);
+    double r = __builtin_fma(-fn, 1.57079632673412561417e+00, x);          // exact (33-bit constant)
+    const double t = r;
+    double w = fn * 6.07710050630396597660e-11;                            // pio2_2
+    r = t - w;
+    w = __builtin_fma(fn, 2.02226624879595063154e-21, -((t - r) - w));     // pio2_2t
+    const double y0 = r - w;
+    const double y1 = (r - y0) - w;
+    const double z = y0 * y0;
+    // __kernel_sin(y0, y1, 1)
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+                 S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double v = z * y0;
+    const double rs = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
+    const double ksin = y0 - ((z * (0.5 * y1 - v * rs) - y1) - v * S1);
+    // __kernel_cos(y0, y1)  (msun form, branch free)
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+                 C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    const double ww = z * z;
+    const double rc = z * (C1 + z * (C2 + z * C3)) + (ww * ww) * (C4 + z * (C5 + z * C6));
+    const double hz = 0.5 * z;
+    const double w1 = 1.0 - hz;
+    const double kcos = w1 + (((1.0 - w1) - hz) + (z * rc - y0 * y1));
+    const int q = (int)fn & 3;
+    const double s_sel = (q & 1) ? kcos : ksin;
+    const double c_sel = (q & 1) ? ksin : kcos;
+    *sn = (q & 2) ? -s_sel : s_sel;
+    *cs = ((q + 1) & 2) ? -c_sel : c_sel;
+}
+#else
+// the faithful flavour calls the device libm; out of line to keep the kernels' code small
+__device__ __noinline__ static double2 sincos_libm_(double y) { double s, c; sincos(y, &s, &c); return make_double2(s, c); }
 UCF_DEV void sincos_(double y, double* s, double* c)
 {
     if (fabs(y) > UCF_DBL_MIN) {
-        sincos(y, s, c);
+        const double2 sc = sincos_libm_(y);
+        *s = sc.x;
+        *c = sc.y;
     } else {
         *s = y;
         *c = 1.0;
     }
 }
+__device__ __noinline__ static double2 coshsinh_libm_(double x) { return make_double2(cosh(x), sinh(x)); }
+#endif
 
 // cosh(x) and sinh(x) for |x| <= 709
 UCF_DEV void coshsinh_(double x, double* ch, double* sh)
@@ -134,7 +195,7 @@ UCF_DEV void coshsinh_(double x, double* ch, double* sh)
     // one exponential for both; below 0.35 the difference form loses bits in sinh -> series
     const double ax = fabs(x);
     const double e = exp(ax);
-    const double ei = 1.0 / e;
+    const double ei = fast_rcp(e);
     *ch = 0.5 * (e + ei);
     double s;
     if (ax < 0.35) {
@@ -154,8 +215,9 @@ UCF_DEV void coshsinh_(double x, double* ch, double* sh)
     }
     *sh = copysign(s, x);
 #else
-    *ch = cosh(x);
-    *sh = sinh(x);
+    const double2 cs_ = coshsinh_libm_(x);
+    *ch = cs_.x;
+    *sh = cs_.y;
 #endif
 }
 
@@ -291,7 +353,13 @@ UCF_DEV cplx csqrt_(cplx x)
             scale = -((53 + 1) / 2);
             re = ldexp(re, -2 * scale); im = ldexp(im, -2 * scale);
         }
+#if UCF_FAST
+        const double ar_ = fabs(re), ai_ = fabs(im);
+        const double mx_ = fmax(ar_, ai_);
+        const double d = (mx_ < 1.0e150 && mx_ > 1.0e-150) ? sqrt(re * re + im * im) : hypot(re, im);
+#else
         const double d = hypot(re, im);
+#endif
         double r, s;
         if (re > 0) {
             r = sqrt(0.5 * (d + re));

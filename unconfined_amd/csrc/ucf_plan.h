@@ -17,6 +17,9 @@ struct ucf_dev_params {
     double lD, dD, bD, dD1, lD1;              // dD1 = 1-dD, lD1 = 1-lD (laplace_hankel_solutions.f90:157-158)
     double MoenchInvGamma[UCF_MAX_MOENCH];    // 1.0/gamma_m (:74)
     double alpha, logtol, maxexp;
+    // fast flavour: hoisted reciprocals, plan-level exact folds, validity bound of the fast evaluation
+    double inv_kappa, inv_bD, fast_eta_max;
+    int fold_dD, fold_lD1, share_g1top, _pad2;
     // Mishra/Neuman (Malama form, :404-442): host-evaluated scalar prefactors
     double mn_vartheta, mn_u0;
     // Mishra/Neuman FD (:444-544)
@@ -47,12 +50,19 @@ struct ucf_plan {
     double* h_gl_x;
     double* h_gl_w;
     int Nv[UCF_MAX_R];
+    // abscissa-table workspace (grown on demand, never shrunk)
+    double* d_work;
+    size_t work_bytes;
 };
 
 // launchers implemented in ucf_kernels.hip (one set per build flavour)
 namespace ucf_faithful {
-int launch_points(const ucf_dev_params& dp, int npts, const double* d_tD, const double* d_rD, const int* d_sv,
-                  double* d_h, double* d_dh, ucf_stats* d_stats, void* stream);
+// abscissa tables (shared by both flavours): tab[row][nabs] of (a, a*J0(a*rD))
+int launch_abscissae(const ucf_dev_params& dp, int nrows, int per_point, int nsv, int svmin, const double* d_rD,
+                     const int* d_sv, double* d_tab, void* stream);
+int launch_points(const ucf_dev_params& dp, int npts, int per_point, int nr, int nsv, int svmin, const double* d_tD,
+                  const double* d_rD, const int* d_sv, const double* d_tab, double* d_h, double* d_dh,
+                  ucf_stats* d_stats, void* stream);
 int launch_samples(const ucf_dev_params& dp, int n_a, const double* d_a, double rD, const double* d_p, double* d_fp,
                    void* stream);
 int launch_dehoog(int n, int M, double alpha, double logtol, const double* d_t, const double* d_tee,
@@ -61,8 +71,9 @@ int launch_wynn(int n, int nterms, const double* d_series, double* d_acc, int* d
 int launch_extrap(int n, int R, const double* d_x, const double* d_y, double* d_out, void* stream);
 }
 namespace ucf_fast {
-int launch_points(const ucf_dev_params& dp, int npts, const double* d_tD, const double* d_rD, const int* d_sv,
-                  double* d_h, double* d_dh, ucf_stats* d_stats, void* stream);
+int launch_points(const ucf_dev_params& dp, int npts, int per_point, int nr, int nsv, int svmin, const double* d_tD,
+                  const double* d_rD, const int* d_sv, const double* d_tab, double* d_h, double* d_dh,
+                  ucf_stats* d_stats, void* stream);
 int launch_samples(const ucf_dev_params& dp, int n_a, const double* d_a, double rD, const double* d_p, double* d_fp,
                    void* stream);
 }

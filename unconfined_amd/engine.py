@@ -121,6 +121,28 @@ class Plan:
             return h, dh, {k: getattr(st, k) for k, _ in UcfStats._fields_}
         return h, dh
 
+    def drawdown_grid(self, tD, sv, rD, zD, zLay, with_stats: bool = False):
+        """product grid nt x nr (the reference's i/k loop nest): h, dh of shape [nt, nr, nz]"""
+        tD, sv, rD, zD, zLay = _f64(tD), _i32(sv), _f64(rD), _f64(zD), _i32(zLay)
+        nt, nr, nz = len(tD), len(rD), len(zD)
+        if len(sv) != nt or len(zLay) != nz:
+            raise ValueError("tD and sv must have equal length; zD and zLay too")
+        h = np.zeros((nt, nr, nz))
+        dh = np.zeros((nt, nr, nz))
+        st = UcfStats()
+        _libmod.check(self._lib.ucf_drawdown_grid(self._h, nt, tD, sv, nr, rD, nz, zD, zLay, h, dh,
+                                                  C.byref(st) if with_stats else None))
+        if with_stats:
+            return h, dh, {k: getattr(st, k) for k, _ in UcfStats._fields_}
+        return h, dh
+
+    def drawdown_grid_device(self, nt: int, d_tD: int, d_sv: int, nr: int, d_rD: int, zD, zLay, d_h: int, d_dh: int,
+                             stream: int = 0, d_stats: int = 0):
+        """asynchronous grid launch on device pointers; outputs [nt][nr][nz]"""
+        zD, zLay = _f64(zD), _i32(zLay)
+        _libmod.check(self._lib.ucf_drawdown_grid_device(self._h, int(nt), d_tD, d_sv, int(nr), d_rD, len(zD), zD, zLay,
+                                                         d_h, d_dh, d_stats or None, stream or None))
+
     def drawdown_device(self, n: int, d_tD: int, d_rD: int, d_sv: int, zD, zLay, d_h: int, d_dh: int,
                         stream: int = 0, d_stats: int = 0):
         """asynchronous launch on device pointers (ints), e.g. torch tensors' data_ptr()"""
@@ -224,9 +246,9 @@ def run_deck(deck_path: str, mode: str = "faithful") -> DeckResult:
     tD, rD, zD = t / D.Tc, r / D.Lc, z / D.Lc
     zl = plan.zlay(zD)
     sv_t = plan.split_vector(tD)
-    TT, RR = np.meshgrid(tD, rD, indexing="ij")
-    SV = np.repeat(sv_t[:, None], len(rD), axis=1)
-    h, dh = plan.drawdown(TT.ravel(), RR.ravel(), SV.ravel(), zD, zl)
+    h, dh = plan.drawdown_grid(tD, sv_t, rD, zD, zl)
+    h = h.reshape(len(tD) * len(rD), len(zD))
+    dh = dh.reshape(len(tD) * len(rD), len(zD))
     sc = 1.0 if dk.dimless else D.Hc
     if dk.timeseries:
         hobs = screen_average_np(h, dk) * sc

@@ -25,7 +25,8 @@ EXPORTS = [
     "ucf_plan_create", "ucf_plan_destroy", "ucf_plan_derived", "ucf_plan_j0z", "ucf_plan_tanh_sinh",
     "ucf_plan_gauss_lobatto", "ucf_plan_set_mode",
     "ucf_logspace", "ucf_linspace", "ucf_zlay", "ucf_split_vector",
-    "ucf_drawdown_batch", "ucf_drawdown_batch_device", "ucf_screen_average",
+    "ucf_drawdown_batch", "ucf_drawdown_batch_device", "ucf_drawdown_grid", "ucf_drawdown_grid_device",
+    "ucf_screen_average",
     "ucf_eval_samples", "ucf_pvalues", "ucf_dehoog", "ucf_wynn_epsilon", "ucf_extraptozero",
     "ucf_fp64_fma_peak",
 ]
@@ -79,6 +80,8 @@ def load() -> C.CDLL:
     lib.ucf_split_vector.argtypes = [vp, C.c_int, _dp, _ip]
     lib.ucf_drawdown_batch.argtypes = [vp, C.c_int, _dp, _dp, _ip, C.c_int, _dp, _ip, _dp, _dp, C.POINTER(UcfStats)]
     lib.ucf_drawdown_batch_device.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int, _dp, _ip, vp, vp, vp, vp]
+    lib.ucf_drawdown_grid.argtypes = [vp, C.c_int, _dp, _ip, C.c_int, _dp, C.c_int, _dp, _ip, _dp, _dp, C.POINTER(UcfStats)]
+    lib.ucf_drawdown_grid_device.argtypes = [vp, C.c_int, vp, vp, C.c_int, vp, C.c_int, _dp, _ip, vp, vp, vp, vp]
     lib.ucf_screen_average.argtypes = [C.c_int, C.c_int, _dp, _dp]
     lib.ucf_eval_samples.argtypes = [vp, C.c_int, _dp, C.c_double, C.c_int, _dp, C.c_int, _dp, _ip, _dp]
     lib.ucf_pvalues.argtypes = [vp, C.c_double, _dp]
