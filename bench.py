@@ -54,6 +54,23 @@ def c2_deck():
                 tval=9999.9, rval=85.1, zTop=146.7, zBot=144.7, zOrd=2, rwobs=0.167, sF=1.0)
 
 
+def workload_deck(name):
+    """BASELINE.json configs; 'c2' is the headline and the default"""
+    from unconfined_amd.deck import Deck
+    c2 = c2_deck()
+    if name == "c2":
+        return c2, 1024, 256, "C2: Neuman-1974 (model 5, beta=0) fully penetrating"
+    if name == "c2pp":     # same sweep, partially penetrating pumping well (cape-cod-neuman74.in geometry)
+        return c2.replace(l=60.2, d=13.2), 1024, 256, "C2pp: Neuman-1974 (model 5, beta=0) partially penetrating"
+    g = Deck.read(os.path.join(ROOT, "tests", "golden", "decks", {"c3": "c3_moench", "c4": "c4_malama_partpen",
+                                                                "c5": "c5_mishra_fd64"}[name] + ".in"))
+    if name == "c3":
+        return g, 2048, 512, "C3: Moench 3-alpha delayed yield, screened observation well (nz=2)"
+    if name == "c4":
+        return g, 4096, 1024, "C4: Malama-2011 partial penetration (beta=2), k=7/R=5, nacc=12"
+    return g, 1024, 256, "C5: Mishra-Neuman finite-difference vadose zone, 64 nodes"
+
+
 def cpu_baseline(dk, ncores):
     """reference-equivalent CPU throughput on a bounded sample: 2 radii x 1024 times of the C2 sweep"""
     from unconfined_amd.deck import TimeSpec
@@ -104,8 +121,9 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--mode", default=os.environ.get("UCF_BENCH_MODE", "fast"), choices=["faithful", "fast"])
-    ap.add_argument("--nt", type=int, default=1024)
-    ap.add_argument("--nr", type=int, default=256)
+    ap.add_argument("--workload", default="c2", choices=["c2", "c2pp", "c3", "c4", "c5"])
+    ap.add_argument("--nt", type=int, default=0)
+    ap.add_argument("--nr", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
@@ -127,7 +145,9 @@ def main():
     from unconfined_amd import engine
     from unconfined_amd.abi import params_from_deck
 
-    dk = c2_deck()
+    dk, nt_def, nr_def, wl_name = workload_deck(args.workload)
+    args.nt = args.nt or nt_def
+    args.nr = args.nr or nr_def
     P = params_from_deck(dk)
     plan = engine.Plan(P, mode=args.mode)
     D = plan.derived
@@ -140,9 +160,9 @@ def main():
     rD_all = 10.0 ** engine.linspace(-1.0, 1.0, nr * world)
     rD_mine = rD_all[rank * nr:(rank + 1) * nr]
     npts = nt * nr
-    zD = np.array([145.7 / D.Lc])
+    zD = engine.linspace(dk.zBot, dk.zTop, 1 if dk.piezometer else dk.zOrd) / D.Lc
     zl = plan.zlay(zD)
-    nz = 1
+    nz = len(zD)
 
     dev = torch.device("cuda", local_rank)
     d_tD = torch.from_numpy(np.ascontiguousarray(tD)).to(dev)                 # [nt]
@@ -194,7 +214,10 @@ def main():
         total_pts = npts * world * args.steps
         value = total_pts / elapsed
         samples_per_pt = D.nabs * D.np * nz
-        flop_per_pt = FLOP_PER_SAMPLE * samples_per_pt + FLOP_TAIL_PER_POINT
+        per_sample = FLOP_PER_SAMPLE if dk.model in (3, 5) else (30.0 if dk.model == 0 else FLOP_PER_SAMPLE)
+        if dk.model == 6 and dk.MNtype == 2:
+            per_sample += dk.order * 68.0            # n*(1 cdiv + 3 cmul + 2 cadd)*2 passes
+        flop_per_pt = per_sample * D.nabs * D.np + 0.35 * per_sample * D.nabs * D.np * (nz - 1) + FLOP_TAIL_PER_POINT * nz
         achieved_tf = flop_per_pt * npts / (kern_ms * 1e-3) * 1e-12
         try:
             fma_peak = engine.fp64_fma_peak()
@@ -213,8 +236,8 @@ def main():
             "value": value, "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"C2: Neuman-1974 (model 5, beta=0) fully penetrating, {nt} log-spaced times x {nr} "
-                                   f"log-spaced radii per GPU, M=26, k=6/R=4, nacc=10, ord=50 ({D.nabs} abscissae, "
+            "config": {"workload": f"{wl_name}, {nt} log-spaced times x {nr} "
+                                   f"log-spaced radii per GPU, M={dk.M}, k={dk.k}/R={dk.R}, nacc={dk.nacc}, ord={dk.ord} ({D.nabs} abscissae, "
                                    f"{samples_per_pt} samples/point)",
                        "points_per_gpu": npts, "mode": args.mode, "partition": "contiguous (t,r) blocks, one rank per GPU",
                        "results_finite_and_gather_consistent": ok},

@@ -185,6 +185,10 @@ int ucf_wynn_epsilon(int n, int nterms, const double* series_re_im /*[n][nterms]
 int ucf_extraptozero(int n, int R, const double* x /*[R]*/, const double* y_re_im /*[n][R]*/,
                      double* out_re_im);
 
+/* K0(z), K1(z), Re z >= 0: cbesk(z, fnu=0, kode=1, n=2), cbessel.f90:877 -> cbknu :5036 (model 2);
+ * k_re_im[n][2][2] = (K0, K1), ierr[n] as cbesk's IERR */
+int ucf_bessel_k01(int n, const double* z_re_im, double* k_re_im, int* ierr);
+
 /* ---- measurement helper: sustained fp64 FMA rate of the device ---- */
 int ucf_fp64_fma_peak(double* tflops);
 

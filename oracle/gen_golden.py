@@ -108,6 +108,15 @@ DECKSET = {
                         M=18, alpha=1.0e-8, tol=1.0e-9, k=10, R=8, j0s=[2, 2], nacc=10, ord=40,
                         tval=5.5, rval=0.25, zTop=4.5, zBot=0.0, zOrd=3, rwobs=0.01, sF=20.0),
                    TimeSpec(True, -1, 8, 30), [None]),
+    # model 2: Hantush with wellbore storage and observation-well delay (needs Amos K0,K1)
+    "hstorage_fullpen_lay1": (mk(MALAMA, model=2, l=52.669, d=0.0, k=6, R=4, j0s=[1, 1], nacc=10, zTop=0.0, zBot=0.0),
+                              TimeSpec(True, -1, 8, 50), [None]),
+    "hstorage_fullpen_lay2": (mk(MALAMA, model=2, l=52.669, d=0.0, k=6, R=4, j0s=[1, 1], nacc=10, zTop=30.0, zBot=20.0),
+                              TimeSpec(True, -1, 8, 50), [None]),
+    "hstorage_partpen_lay1": (mk(MALAMA, model=2, l=40.0, d=10.0, k=6, R=4, j0s=[1, 1], nacc=10, zTop=10.0, zBot=0.0, rw=0.5, rwobs=0.3),
+                              TimeSpec(True, -1, 8, 50), [None]),
+    "hstorage_partpen_lay2": (mk(MALAMA, model=2, l=40.0, d=10.0, k=6, R=4, j0s=[1, 1], nacc=10, zTop=35.0, zBot=25.0, rw=0.5, rwobs=0.3),
+                              TimeSpec(True, -1, 8, 50), [None]),
     # pumping-schedule variants (time.f90:50-80)
     "theis_pulse": (mk(SMALL, model=0, l=7.5, d=2.5, timeType=2, timePar=[0.0, 50.0]), TimeSpec(True, -1, 6, 40), [None]),
     "theis_stairs": (mk(SMALL, model=0, l=7.5, d=2.5, timeType=4, timePar=[100.0, 1000.0]), TimeSpec(True, -1, 6, 40), [None]),
@@ -135,7 +144,7 @@ def parse_dump(text):
     out = []
     i = 0
     # skip anything read_input printed before the first tag we know
-    tags = {"params", "pvalues", "soln", "tanhsinh", "gausslobatto", "wynn", "extrap", "dehoog"}
+    tags = {"params", "pvalues", "soln", "tanhsinh", "gausslobatto", "wynn", "extrap", "dehoog", "cbesk"}
     while i < len(lines):
         parts = lines[i].split()
         if not parts or parts[0] not in tags:
@@ -159,6 +168,8 @@ def parse_dump(text):
         elif tag in ("tanhsinh", "gausslobatto"):
             n = 2 * hdr[0]
             out.append((tag, hdr, lines[i:i + n])); i += n
+        elif tag == "cbesk":
+            out.append((tag, hdr, lines[i:i + 2])); i += 2
         else:
             out.append((tag, hdr, lines[i:i + 1])); i += 1
     return out
@@ -323,6 +334,13 @@ def run_generic_stages(workdir, flavour="O2"):
                 cmds.append(f"dehoog {hx(t)} {hx(tee)}")
                 cmds += [f"{hx(z.real)} {hx(z.imag)}" for z in fp]
                 dh_in.append((M, alpha, tol, t, tee, fp))
+    # Amos K0/K1 (cbessel.f90:877): both branches (|z| <= 2 series, > 2 Miller), right half plane
+    kz = []
+    for mag in (1e-12, 1e-6, 1e-3, 0.05, 0.7, 1.9, 2.0, 2.0000001, 2.7, 5.0, 12.0, 28.0, 29.0, 60.0, 300.0):
+        for ang in (0.0, 0.3, 0.78, 1.2, 1.5, -0.6, -1.45):
+            z = mag * np.exp(1j * ang)
+            kz.append(z)
+            cmds.append(f"cbesk {hx(z.real)} {hx(z.imag)}")
     text = subprocess.run([os.path.join(REFBIN[flavour], "ref_harness"), f"{name}.in"], input="\n".join(cmds) + "\n",
                           capture_output=True, text=True, cwd=workdir, check=True).stdout
     recs = [r for r in parse_dump(text)]
@@ -342,6 +360,14 @@ def run_generic_stages(workdir, flavour="O2"):
         arrs[f"dehoog_par_{i}"] = np.array([M, alpha, tol, t, tee])
         arrs[f"dehoog_fp_{i}"] = np.stack([fp.real, fp.imag], -1)
         arrs[f"dehoog_out_{i}"] = rvec(body)
+    kout, kerr = [], []
+    for z in kz:
+        tag, hdr, body = next(it); assert tag == "cbesk"
+        kerr.append(hdr)
+        kout.append(cvec(body))
+    arrs["cbesk_z"] = np.array([[z.real, z.imag] for z in kz])
+    arrs["cbesk_k"] = np.stack(kout)                 # [n][2][2]: K0, K1
+    arrs["cbesk_nz_ierr"] = np.array(kerr)
     arrs["counts"] = np.array([len(wy_in), len(ex_in), len(dh_in)])
     np.savez_compressed(os.path.join(GOLD, "stages_generic.npz"), **arrs)
 

@@ -13,6 +13,7 @@
 !   wynn_epsilon          (/root/reference/integration.f90:125)-> "wynn"
 !   extraptozero          (/root/reference/integration.f90:192)-> "extrap"
 !   deHoog_invlap         (/root/reference/invlap.f90:34)      -> "dehoog"
+!   cbesk                 (/root/reference/cbessel.f90:877)    -> "cbesk"
 !
 ! usage:  ref_harness <deck> < commands > dump
 ! The deck is parsed by the reference's own read_input (it takes argv(1)), so
@@ -25,6 +26,7 @@ program ref_harness
   use laplace_hankel_solutions, only : lap_hank_soln
   use invlap, only : deHoog_invlap, deHoog_pvalues
   use integration, only : tanh_sinh_setup, gauss_lobatto_setup, wynn_epsilon, extraptozero
+  use cbessel, only : cbesk
   implicit none
 
   type(invLaplace) :: l
@@ -47,6 +49,8 @@ program ref_harness
   real(EP) :: ft
   type(TanhSinh) :: t2
   type(GaussLobatto) :: g2
+  complex(DP) :: zk, kk(2)
+  integer :: nzk, ierrk
 
   call read_input(w,f,s,l,h,gl,ts)
   l%np = 2*l%M + 1
@@ -149,6 +153,13 @@ program ref_harness
         write(*,'(A)') 'dehoog'
         write(*,'(Z16.16)') r2hex(ft)
         deallocate(vec)
+
+     case ('cbesk')            ! cbesk re(hex) im(hex): K0,K1 by the reference's Amos routine (cbessel.f90:877)
+        zk = cmplx(hex2r(tok(2)), hex2r(tok(3)), DP)
+        kk = (0.0_DP, 0.0_DP)
+        call cbesk(z=zk, fnu=0.0_DP, kode=1, n=2, cy=kk, nz=nzk, ierr=ierrk)
+        write(*,'(A,2(1X,I0))') 'cbesk', nzk, ierrk
+        call dump_cvec(cmplx(kk, kind=EP), 2)
 
      case default
         write(*,'(A)') 'unknown '//trim(cmd)

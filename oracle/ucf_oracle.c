@@ -43,6 +43,8 @@ typedef __float128 R;
 #define r_sinh sinhq
 #define r_tanh tanhq
 #define r_cos cosq
+#define r_sin sinq
+#define r_atan2 atan2q
 #define r_atan atanq
 #define r_floor floorq
 #define r_ceil ceilq
@@ -73,6 +75,8 @@ typedef double R;
 #define r_sinh sinh
 #define r_tanh tanh
 #define r_cos cos
+#define r_sin sin
+#define r_atan2 atan2
 #define r_atan atan
 #define r_floor floor
 #define r_ceil ceil
@@ -151,6 +155,7 @@ static inline C c_exp(C z) { return fromq(cexpq(toq(z))); }
 static inline C c_cosh(C z) { return fromq(ccoshq(toq(z))); }
 static inline C c_sinh(C z) { return fromq(csinhq(toq(z))); }
 static inline R c_abs(C z) { return cabsq(toq(z)); }
+static inline C c_log(C z) { return fromq(clogq(toq(z))); }
 #else
 static inline double complex tod(C z) { return CMPLX(z.re, z.im); }
 static inline C fromd(double complex w) { return c_make(creal(w), cimag(w)); }
@@ -159,6 +164,7 @@ static inline C c_exp(C z) { return fromd(cexp(tod(z))); }
 static inline C c_cosh(C z) { return fromd(ccosh(tod(z))); }
 static inline C c_sinh(C z) { return fromd(csinh(tod(z))); }
 static inline R c_abs(C z) { return cabs(tod(z)); }
+static inline C c_log(C z) { return fromd(clog(tod(z))); }
 #endif
 
 static inline int c_isnan_part(C z) { return r_isnan(z.re) || r_isnan(z.im); }
@@ -543,6 +549,161 @@ void ucfo_extraptozero(int n, const double* x, const double* y_re_im, double* ou
     st(out_re_im, 0, extrap_R(n, xr, yr));
 }
 
+
+/* ---------------------------------------------------------- K0, K1 (Amos) */
+/* cbesk(z, fnu=0, kode=1, n=2) for Re z >= 0: cbessel.f90:877-1146 -> cbknu :5036-5495.
+ * Only the branches that fnu = 0, n = 2, kode = 1 can reach are restated:
+ *   |z| <= 2 : power series (:5098-5201);  |z| > 2 : Miller backward recurrence (:5209-5327).
+ * Returns ierr as cbesk does (0 ok; 1 bad input; 2 overflow; 4/5 range/convergence). */
+static int cbesk01_R(C z, C* k0, C* k1)
+{
+    const R tol = (R)DBL_EPSILON;            /* MAX(EPSILON, 1e-18) of the binary64 reference build */
+    const R elim = RC(2.303) * ((R)1021 * r_log10(RC(2.0)) - RC(3.0));
+    const R aa0 = r_log10(RC(2.0)) * (R)52;
+    const R alim = elim + r_fmax(-(aa0 * RC(2.303)), RC(-41.45));
+    /* cbessel.f90:20-25: derived from atan(1) in working precision, not literals */
+    const R at1 = RC(0.78539816339744830961566084581987572);
+    const R pi = RC(4.0) * at1, hpi = RC(2.0) * at1, spi = RC(3.0) / (RC(2.0) * at1);
+    const R rthpi = r_sqrt(RC(8.0) * at1) / RC(2.0);
+    const R fpi = RC(1.89769999331517738), tth = RC(6.66666666666666666e-01);
+    const R gamma_e = RC(5.77215664901532861e-01);
+    const R xx = z.re, yy = z.im;
+    *k0 = c_make(RC(0.0), RC(0.0));
+    *k1 = *k0;
+    if (r_fabs(yy) == RC(0.0) && r_fabs(xx) == RC(0.0)) return 1;
+    const R az = c_abs(z);
+    {   /* range tests of cbesk :1061-1078 */
+        R a = RC(0.5) / tol, b = (R)2147483647 * RC(0.5);
+        if (b < a) a = b;
+        if (az > a) return 4;
+        if (az < (R)DBL_MIN * RC(1.0e3)) return 2;
+        /* fn = 1 <= 2: only the az <= tol overflow test applies (:1082-1087) */
+        if (!(az > tol)) { R aln = -RC(1.0) * r_log(RC(0.5) * az); if (aln > elim) return 2; }
+    }
+    const R caz = az;
+    const C rz = c_div(c_make(RC(2.0), RC(0.0)), z);                      /* :5085 */
+    C s1, s2;
+    if (caz <= RC(2.0)) {                                                 /* :5098 */
+        const C smu = c_log(rz);
+        C f = c_add(c_make(-gamma_e, RC(0.0)), smu);                      /* g1*cch + smu*g2, g1=-gamma, cch=1, g2=1 */
+        /* exactly as the reference orders it: f = g1*cch + smu*g2 with cch = (1,0): g1*cch = (g1*1, g1*0) */
+        f = c_add(c_rscale(-gamma_e, c_make(RC(1.0), RC(0.0))), c_scale(smu, RC(1.0)));
+        C p = c_make(RC(0.5), RC(0.0)), q = c_make(RC(0.5), RC(0.0));
+        s1 = f;
+        s2 = p;
+        R ak = RC(1.0), a1 = RC(1.0), bk = RC(1.0);
+        C ck = c_make(RC(1.0), RC(0.0));
+        if (caz >= tol) {
+            const C cz = c_scale(c_mul(z, z), RC(0.25));
+            const R t1 = RC(0.25) * caz * caz;
+            do {                                                          /* :5172-5182 */
+                f = c_divr(c_add(c_add(c_scale(f, ak), p), q), bk);
+                p = c_divr(p, ak);            /* ak - dnu, dnu = 0 */
+                q = c_divr(q, ak);
+                const R rk = RC(1.0) / ak;
+                ck = c_scale(c_mul(ck, cz), rk);
+                s1 = c_add(s1, c_mul(ck, f));
+                s2 = c_add(s2, c_mul(ck, c_sub(p, c_scale(f, ak))));
+                a1 = a1 * t1 * rk;
+                bk = bk + ak + ak + RC(1.0);
+                ak = ak + RC(1.0);
+            } while (a1 > tol);
+        }
+        /* kflag = 2 unless (fnu+1)*|Re smu| > alim (never for |z| > 1e-288) */
+        s2 = c_mul(s2, rz);                                               /* p2 = s2*css(2); s2 = p2*rz */
+        *k0 = s1;
+        *k1 = s2;
+        return 0;
+    }
+    /* |z| > 2: :5209-5327 */
+    if (xx > alim) return 2;      /* the scaled-exponential continuation (:5476-5479) is not restated: |K| < 1e-288 */
+    C coef = c_div(c_make(rthpi, RC(0.0)), c_sqrt(z));
+    {
+        const R a1 = r_exp(-xx);
+        const C pt = c_rscale(a1, c_make(r_cos(yy), -r_sin(yy)));
+        coef = c_mul(coef, pt);
+    }
+    R ak = r_fabs(r_cos(pi * RC(0.0)));
+    R fhs = RC(0.25);
+    R t1 = (R)52 * r_log10(RC(2.0)) * RC(3.321928094);
+    if (t1 < RC(12.0)) t1 = RC(12.0);
+    if (t1 > RC(60.0)) t1 = RC(60.0);
+    R t2 = tth * t1 - RC(6.0);
+    if (xx == RC(0.0)) t1 = hpi;
+    else t1 = r_fabs(r_atan(yy / xx));
+    R fk;
+    if (t2 <= caz) {
+        const R etest = ak / (pi * caz * tol);
+        fk = RC(1.0);
+        if (!(etest < RC(1.0))) {
+            R fks = RC(2.0), rk = caz + caz + RC(2.0), a1 = RC(0.0), a2 = RC(1.0);
+            int found = 0;
+            for (int i = 1; i <= 30; i++) {
+                ak = fhs / fks;
+                const R bk = rk / (fk + RC(1.0));
+                R tm = a2;
+                a2 = bk * a2 - ak * a1;
+                a1 = tm;
+                rk = rk + RC(2.0);
+                fks = fks + fk + fk + RC(2.0);
+                fhs = fhs + fk + fk;
+                fk = fk + RC(1.0);
+                tm = r_fabs(a2) * fk;
+                if (etest < tm) { found = 1; break; }
+            }
+            if (!found) return 5;
+            fk = fk + spi * t1 * r_sqrt(t2 / caz);
+            fhs = RC(0.25);
+        }
+    } else {
+        const R a2 = r_sqrt(caz);
+        ak = fpi * ak / (tol * r_sqrt(a2));
+        const R aa = RC(3.0) * t1 / (RC(1.0) + caz);
+        const R bb = RC(14.7) * t1 / (RC(28.0) + caz);
+        ak = (r_log(ak) + caz * r_cos(aa) / (RC(1.0) + RC(0.008) * caz)) / r_cos(bb);
+        fk = RC(0.12125) * ak * ak / caz + RC(1.5);
+    }
+    const int k = (int)fk;
+    fk = (R)k;
+    R fks = fk * fk;
+    C p1 = c_make(RC(0.0), RC(0.0)), p2 = c_make(tol, RC(0.0)), cs = p2;
+    for (int i = 1; i <= k; i++) {                                        /* :5279-5291 */
+        const R a1 = fks - fk;
+        const R a2 = (fks + fk) / (a1 + fhs);
+        const R rk = RC(2.0) / (fk + RC(1.0));
+        const R tt1 = (fk + xx) * rk, tt2 = yy * rk;
+        const C pt = p2;
+        p2 = c_scale(c_sub(c_mul(p2, c_make(tt1, tt2)), p1), a2);
+        p1 = pt;
+        cs = c_add(cs, p2);
+        fks = a1 - fk + RC(1.0);
+        fk = fk - RC(1.0);
+    }
+    R tm = c_abs(cs);
+    C pt = c_make(RC(1.0) / tm, RC(0.0));
+    s1 = c_mul(pt, p2);
+    cs = c_mul(c_make(cs.re, -cs.im), pt);
+    s1 = c_mul(c_mul(coef, s1), cs);
+    tm = c_abs(p2);
+    pt = c_make(RC(1.0) / tm, RC(0.0));
+    p1 = c_mul(pt, p1);
+    p2 = c_mul(c_make(p2.re, -p2.im), pt);
+    pt = c_mul(p1, p2);
+    s2 = c_mul(s1, c_add(c_make(RC(1.0), RC(0.0)), c_div(c_sub(c_make(RC(0.5), RC(0.0)), pt), z)));
+    *k0 = s1;
+    *k1 = s2;
+    return 0;
+}
+
+int ucfo_cbesk01(double zr, double zi, double* k_re_im /* K0re,K0im,K1re,K1im */)
+{
+    C k0, k1;
+    int ierr = cbesk01_R(c_make((R)zr, (R)zi), &k0, &k1);
+    st(k_re_im, 0, k0);
+    st(k_re_im, 1, k1);
+    return ierr;
+}
+
 /* ------------------------------------------------ Laplace-Hankel evaluators */
 typedef struct {
     int model, MNtype, order, timeType, MoenchM;
@@ -550,6 +711,7 @@ typedef struct {
     R kappa, alphaD, beta, lD, dD, bD;
     R MoenchGamma[UCF_MAX_MOENCH];
     R Sy, Ss, b, ak, ac, psia, psik, b1, akD, lambdaD, usLD;
+    R rDw, rDwobs, sF, screen;   /* model 2: screen = l - d (dimensional) */
     R maxexp;
 } mdl;
 
@@ -564,6 +726,7 @@ static void mdl_fill(mdl* m, const ucf_params* P, const ucf_derived* D)
     m->Sy = (R)P->Sy; m->Ss = (R)P->Ss; m->b = (R)P->b; m->ak = (R)P->ak; m->ac = (R)D->ac_eff;
     m->psia = (R)P->psia; m->psik = (R)P->psik; m->b1 = (R)D->b1; m->akD = (R)D->akD;
     m->lambdaD = (R)D->lambdaD; m->usLD = (R)D->usLD;
+    m->rDw = (R)D->rDw; m->rDwobs = (R)D->rDwobs; m->sF = (R)P->sF; m->screen = (R)D->l_eff - (R)D->d_eff;
     m->maxexp = (R)ucfo_maxexp();
 }
 
@@ -620,6 +783,38 @@ static C hantush_s(const mdl* m, R a, C p, R zD, int lay)
     return c_divr(c_mul(udp, theis_s(a, p)), m->bD);
 }
 
+/* laplace_hankel_solutions.f90:204-301, one p, all z.  The reference leaves ff(1:2) unassigned for
+ * depths above the screen (zLay = 3, its WHERE masks at :273-276) and then uses them at :278-282 --
+ * undefined there; here they are always computed (the Hantush expressions), so parity with the
+ * reference is claimed for layers 1 and 2 only. */
+static void hantush_storage_p(const mdl* m, R a, C p, int nz, const R* zD, const int* zLay, C* u)
+{
+    const R dD1 = RC(1.0) - m->dD, lD1 = RC(1.0) - m->lD;
+    const R CDw = m->rDw * m->rDw / (RC(2.0) * m->screen * m->Ss);        /* :250 */
+    const R tDb = PI_R * (m->rDwobs * m->rDwobs) / (m->sF * m->Ss);       /* :253 */
+    const C xi = c_rscale(m->rDw, c_sqrt(p));                             /* :255 */
+    const C eta = c_sqrt(c_divr(c_addr(p, a * a), m->kappa));             /* :256 */
+    C K0, K1;
+    cbesk01_R(xi, &K0, &K1);                                              /* :258-265 */
+    const C A0 = c_rdiv(RC(2.0), c_add(c_mul(c_scale(p, CDw), K0), c_mul(xi, K1)));   /* :267 */
+    const C uDf = c_div(A0, c_mul(c_addr(p, a * a), c_addr(c_scale(p, tDb), RC(1.0))));   /* :268 */
+    const C ff1 = c_sinh(c_scale(eta, m->dD)), ff2 = c_sinh(c_scale(eta, lD1)), sh = c_sinh(eta);
+    const C pre = c_divr(uDf, m->bD);
+    for (int k = 0; k < nz; k++) {
+        C uDp;
+        if (zLay[k] == 1) {
+            C ff3 = c_sub(c_exp(c_neg(c_scale(eta, lD1))), c_div(c_add(ff1, c_mul(c_exp(c_neg(eta)), ff2)), sh));
+            uDp = c_mul(ff3, c_cosh(c_scale(eta, zD[k])));
+        } else {
+            C g2 = c_div(c_add(c_mul(ff1, c_cosh(c_scale(eta, zD[k]))),
+                               c_mul(ff2, c_cosh(c_scale(eta, RC(1.0) - zD[k])))), sh);
+            if (zLay[k] == 2) uDp = c_rsub(RC(1.0), g2);
+            else uDp = c_sub(c_cosh(c_scale(eta, dD1 - zD[k])), g2);
+        }
+        u[k] = c_mul(pre, uDp);                                           /* :299 */
+    }
+}
+
 /* complex Thomas algorithm, utility.f90:96-135, for one p */
 static void tridiag_s(int n, const C* a, const C* b, const C* c, const C* v, C* x, C* bp, C* vp)
 {
@@ -645,6 +840,9 @@ static int soln_p(const mdl* m, R a, R rD, C p, int nz, const R* zD, const int* 
         break;
     case 1:
         for (int k = 0; k < nz; k++) fp[k] = hantush_s(m, a, p, zD[k], zLay[k]);
+        break;
+    case 2:
+        hantush_storage_p(m, a, p, nz, zD, zLay, fp);
         break;
     case 3: case 4: case 5: {                                              /* :64-93 */
         C eta = c_sqrt(c_divr(c_addr(p, a * a), m->kappa));

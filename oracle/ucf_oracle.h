@@ -52,6 +52,9 @@ void ucfo_wynn_epsilon(int n, const double* series_re_im, double* acc_re_im, int
 /* integration.f90:192-237 */
 void ucfo_extraptozero(int n, const double* x, const double* y_re_im, double* out_re_im);
 
+/* cbesk(z, fnu=0, kode=1, n=2): cbessel.f90:877 -> cbknu :5036; returns ierr */
+int ucfo_cbesk01(double zr, double zi, double* k_re_im);
+
 /* laplace_hankel_solutions.f90:30-120; fp[nz][np] complex (column-major like fp(np,nz)) */
 int ucfo_lap_hank_soln(const ucf_params* P, const ucf_derived* D, double a, double rD,
                        int np, const double* p_re_im, int nz, const double* zD, const int* zLay,

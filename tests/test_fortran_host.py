@@ -46,7 +46,10 @@ def test_fortran_host_rows_match_reference(tmp_path, name):
     res, dk = _run(tmp_path, name)
     assert res.returncode == 0, res.stdout + res.stderr
     rows = np.array([[float(x) for x in ln.split()[:3]] for ln in open(tmp_path / dk.outFileName) if not ln.startswith("#")])
-    ref = load_e2e(name)["O2_r0"]
+    e2e = load_e2e(name)
+    ir = int(np.argmin(np.abs(e2e["radii"] - dk.rval)))          # the fixture row of the deck's own radius
+    assert e2e["radii"][ir] == dk.rval
+    ref = e2e[f"O2_r{ir}"]
     assert rows.shape == ref.shape
     assert np.array_equal(rows[:, 0], ref[:, 0])                      # the time column is printed identically
     assert rel_err(rows[:, 1], ref[:, 1], 1e-3).max() < 1e-8

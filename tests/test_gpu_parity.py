@@ -94,6 +94,20 @@ def test_extraptozero_bit_exact(engine):
         assert bits_equal(out[0], z[f"extrap_out_{i}"]), ("extrap", i)
 
 
+def test_bessel_k0_k1(engine):
+    """a9: Amos K0/K1 (series and Miller branches) on the device against the reference's cbesk"""
+    z = np.load(os.path.join(GOLD, "stages_generic.npz"))
+    k, ierr = engine.bessel_k01(z["cbesk_z"])
+    ref, ref_err = z["cbesk_k"], z["cbesk_nz_ierr"][:, 1]
+    ok = ref_err == 0
+    assert np.array_equal(ierr[ok], np.zeros(ok.sum(), np.int32))
+    assert np.all(ierr[~ok] != 0)
+    zr = ref[..., 0] + 1j * ref[..., 1]
+    zg = k[..., 0] + 1j * k[..., 1]
+    rel = np.abs(zg - zr)[ok] / np.abs(zr)[ok]
+    assert rel.max() < 5e-15, float(rel.max())
+
+
 def test_dehoog_few_ulp(engine):
     """a15: QD table + continued fraction across lanes; cexp/csqrt/exp are device libm -> 1e-13 relative"""
     z = np.load(os.path.join(GOLD, "stages_generic.npz"))

@@ -94,6 +94,30 @@ def test_wynn_extrap_dehoog_bit_exact(oracle):
         assert bits_equal(np.array([out]), z[f"dehoog_out_{i}"]), ("dehoog", i)
 
 
+def test_cbesk_k0_k1_bit_exact(oracle):
+    """Amos cbesk/cbknu for (fnu=0, n=2, kode=1), cbessel.f90:877,5036: power series for |z| <= 2 and
+    Miller backward recurrence beyond, against the reference's routine on 105 right-half-plane points"""
+    import ctypes as C
+    import os
+    from golden_util import GOLD
+    z = np.load(os.path.join(GOLD, "stages_generic.npz"))
+    lib = oracle.lib
+    lib.ucfo_cbesk01.argtypes = [C.c_double, C.c_double, np.ctypeslib.ndpointer(np.float64)]
+    nbad = 0
+    for i, (zr, zi) in enumerate(z["cbesk_z"]):
+        out = np.zeros(4)
+        ierr = lib.ucfo_cbesk01(float(zr), float(zi), out)
+        nzr, ierr_ref = z["cbesk_nz_ierr"][i]
+        if ierr_ref != 0:
+            assert ierr != 0
+            continue
+        assert ierr == 0, (zr, zi)
+        if not bits_equal(out.reshape(2, 2), z["cbesk_k"][i]):
+            nbad += 1
+            assert np.max(np.abs(out.reshape(2, 2) - z["cbesk_k"][i]) / np.abs(z["cbesk_k"][i]).max()) < 4e-16, (zr, zi)
+    assert nbad <= 3, nbad       # a handful of points differ in the last bit (libm pow/log paths), none by more
+
+
 def _oracle_rows(oracle, name, ir, e2e):
     dk, ts, P = load_deck(name)
     P.l = dk.l  # noqa

@@ -85,7 +85,8 @@ int validate(const ucf_params& P)
     if (P.j0s[0] < 1 || P.j0s[1] < 1 || P.nacc < 1 || P.k < 1)
         return fail(UCF_ERR_GAUSS_LOBATTO, "min/max split, # accelerated terms and k must be >= 1");
     if (P.ord < 3) return fail(UCF_ERR_GAUSS_LOBATTO, "Gauss-Lobatto order must be >= 3");
-    if (P.model == 2) return fail(UCF_ERR_UNSUPPORTED, "model 2 (Hantush with wellbore storage) is not built yet");
+    if (P.model == 2 && (P.rwobs <= 0.0 || P.sF <= 0.0))
+        return fail(UCF_ERR_OBSERVATION, "model 2 needs a positive observation-well radius and shape factor");   // driver_io.f90:374-383
     if (P.timeType < 1 || P.timeType > 8) return fail(UCF_ERR_UNSUPPORTED, "time behaviour %d is not built (1..8 are)", P.timeType);
     return UCF_OK;
 }
@@ -285,6 +286,12 @@ int ucf_plan_create(const ucf_params* Pin, ucf_plan** out)
         dp.fd_beta0 = D.ac_eff * P.Sy / P.Ss;
         dp.fd_beta3 = D.akD;
         dp.fd_expmb2 = std::exp(-(P.ak * D.b1));
+    }
+    if (P.model == 2) {                                               // laplace_hankel_solutions.f90:250-253
+        const double PI = 4.0 * std::atan(1.0);
+        dp.hs_rDw = D.rDw;
+        dp.hs_CDw = D.rDw * D.rDw / (2.0 * (D.l_eff - D.d_eff) * P.Ss);
+        dp.hs_tDb = PI * (D.rDwobs * D.rDwobs) / (P.sF * P.Ss);
     }
     if (P.model == 6 && P.MNtype == 1) {                              // :420-427
         const double beta0 = P.ak * P.b;
@@ -664,6 +671,23 @@ int ucf_dehoog(int n, int M, double alpha, double tol, const double* t, const do
     if (rc) return fail(rc, "de Hoog kernel launch failed");
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(ft, b_o.p, sizeof(double) * n, hipMemcpyDeviceToHost));
+    return UCF_OK;
+}
+
+int ucf_bessel_k01(int n, const double* z, double* k, int* ierr)
+{
+    if (n < 1 || !z || !k || !ierr) return fail(UCF_ERR_BAD_ARGUMENT, "bad Bessel request");
+    int rc = require_device();
+    if (rc) return rc;
+    dev_buf b_z, b_k, b_e;
+    if (b_z.alloc(sizeof(double) * 2 * n) || b_k.alloc(sizeof(double) * 4 * n) || b_e.alloc(sizeof(int) * n))
+        return fail(UCF_ERR_NOMEM, "device allocation failed");
+    HIP_TRY(hipMemcpy(b_z.p, z, sizeof(double) * 2 * n, hipMemcpyHostToDevice));
+    rc = ucf_faithful::launch_bessel(n, (const double*)b_z.p, (double*)b_k.p, (int*)b_e.p, nullptr);
+    if (rc) return fail(rc, "Bessel kernel launch failed");
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(k, b_k.p, sizeof(double) * 4 * n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(ierr, b_e.p, sizeof(int) * n, hipMemcpyDeviceToHost));
     return UCF_OK;
 }
 

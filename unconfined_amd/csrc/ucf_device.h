@@ -48,6 +48,15 @@ UCF_DEV void lds_st(lds_c* base, int slot, int lane, cplx z) { base[slot * UCF_W
 UCF_DEV cplx scr_ld(const lds_c* base, int slot, int lane) { lds_c v = base[slot * (UCF_WAVE / 2) + (lane & 31)]; return cmake(v.x, v.y); }
 UCF_DEV void scr_st(lds_c* base, int slot, int lane, cplx z) { base[slot * (UCF_WAVE / 2) + (lane & 31)] = make_double2(z.re, z.im); }
 
+#if UCF_FAST
+// 1/z without exponent scaling (|z| well inside [1e-150, 1e150])
+UCF_DEV cplx cinv_plain_(cplx z)
+{
+    const double r = fast_rcp(z.re * z.re + z.im * z.im);
+    return cmake(z.re * r, -(z.im * r));
+}
+#endif
+
 // ------------------------------------------------------------------ time.f90:34-80
 UCF_DEV cplx lap_time(const ucf_dev_params& P, cplx p)
 {
@@ -73,6 +82,141 @@ UCF_DEV cplx lap_time(const ucf_dev_params& P, cplx p)
     }
 }
 
+// ------------------------------------------------------------------ cbessel.f90:877,5036
+// K0(z), K1(z) for Re z >= 0 by the Amos algorithm (cbesk -> cbknu with fnu = 0, n = 2, kode = 1):
+// power series for |z| <= 2 (:5098-5201), Miller backward recurrence beyond (:5209-5327).
+// Evaluated once per lane and point (z = rDw*sqrt(p) does not depend on the abscissa).
+struct k01 { cplx k0, k1; int ierr; };
+UCF_DEV cplx clog_(cplx z) { return cmake(log(hypot(z.re, z.im)), atan2(z.im, z.re)); }
+
+__device__ __noinline__ static k01 cbesk01_(cplx z)
+{
+    k01 out;
+    out.k0 = cmake(0.0, 0.0); out.k1 = out.k0; out.ierr = 0;
+    const double tol = UCF_EPS;
+    const double elim = 2.303 * (1021.0 * log10(2.0) - 3.0);
+    const double alim = elim + fmax(-(log10(2.0) * 52.0 * 2.303), -41.45);
+    const double at1 = 0.78539816339744830962;
+    const double pi = 4.0 * at1, hpi = 2.0 * at1, spi = 3.0 / (2.0 * at1);
+    const double rthpi = sqrt(8.0 * at1) / 2.0, fpi = 1.89769999331517738, tth = 6.66666666666666666e-01;
+    const double gamma_e = 5.77215664901532861e-01;
+    const double xx = z.re, yy = z.im;
+    if (xx == 0.0 && yy == 0.0) { out.ierr = 1; return out; }
+    const double caz = hypot(xx, yy);
+    if (caz > 1073741823.5) { out.ierr = 4; return out; }
+    if (caz < UCF_DBL_MIN * 1.0e3) { out.ierr = 2; return out; }
+    if (!(caz > tol) && -log(0.5 * caz) > elim) { out.ierr = 2; return out; }
+    const cplx rz = cdiv(cmake(2.0, 0.0), z);                                                   // :5085
+    cplx s1, s2;
+    if (caz <= 2.0) {
+        const cplx smu = clog_(rz);
+        cplx f = cadd(rscale(-gamma_e, cmake(1.0, 0.0)), cscale(smu, 1.0));                     // :5137
+        cplx p = cmake(0.5, 0.0), q = cmake(0.5, 0.0);
+        s1 = f; s2 = p;
+        double ak = 1.0, a1 = 1.0, bk = 1.0;
+        cplx ck = cmake(1.0, 0.0);
+        if (caz >= tol) {
+            const cplx cz = cscale(cmul(z, z), 0.25);
+            const double t1 = 0.25 * caz * caz;
+            do {                                                                                // :5172-5182
+                f = cdivr(cadd(cadd(cscale(f, ak), p), q), bk);
+                p = cdivr(p, ak);
+                q = cdivr(q, ak);
+                const double rk = 1.0 / ak;
+                ck = cscale(cmul(ck, cz), rk);
+                s1 = cadd(s1, cmul(ck, f));
+                s2 = cadd(s2, cmul(ck, csub(p, cscale(f, ak))));
+                a1 = a1 * t1 * rk;
+                bk = bk + ak + ak + 1.0;
+                ak = ak + 1.0;
+            } while (a1 > tol);
+        }
+        out.k0 = s1;
+        out.k1 = cmul(s2, rz);
+        return out;
+    }
+    if (xx > alim) { out.ierr = 2; return out; }
+    cplx coef = cdiv(cmake(rthpi, 0.0), csqrt_(z));
+    {
+        double sn, cs;
+        sincos_(yy, &sn, &cs);
+        coef = cmul(coef, rscale(exp(-xx), cmake(cs, -sn)));
+    }
+    double ak = fabs(cos(pi * 0.0));
+    double fhs = 0.25;
+    double t1 = 52.0 * log10(2.0) * 3.321928094;
+    t1 = fmin(fmax(t1, 12.0), 60.0);
+    const double t2 = tth * t1 - 6.0;
+    t1 = (xx == 0.0) ? hpi : fabs(atan(yy / xx));
+    double fk;
+    if (t2 <= caz) {
+        const double etest = ak / (pi * caz * tol);
+        fk = 1.0;
+        if (!(etest < 1.0)) {
+            double fks = 2.0, rk = caz + caz + 2.0, a1 = 0.0, a2 = 1.0;
+            bool found = false;
+            for (int i = 1; i <= 30 && !found; i++) {
+                ak = fhs / fks;
+                const double bk = rk / (fk + 1.0);
+                double tm = a2;
+                a2 = bk * a2 - ak * a1;
+                a1 = tm;
+                rk = rk + 2.0;
+                fks = fks + fk + fk + 2.0;
+                fhs = fhs + fk + fk;
+                fk = fk + 1.0;
+                tm = fabs(a2) * fk;
+                if (etest < tm) found = true;
+            }
+            if (!found) { out.ierr = 5; return out; }
+            fk = fk + spi * t1 * sqrt(t2 / caz);
+            fhs = 0.25;
+        }
+    } else {
+        const double a2 = sqrt(caz);
+        ak = fpi * ak / (tol * sqrt(a2));
+        const double aa = 3.0 * t1 / (1.0 + caz);
+        const double bb = 14.7 * t1 / (28.0 + caz);
+        ak = (log(ak) + caz * cos(aa) / (1.0 + 0.008 * caz)) / cos(bb);
+        fk = 0.12125 * ak * ak / caz + 1.5;
+    }
+    const int k = (int)fk;
+    fk = (double)k;
+    double fks = fk * fk;
+    cplx p1 = cmake(0.0, 0.0), p2 = cmake(tol, 0.0), cs = p2;
+    for (int i = 1; i <= k; i++) {                                                              // :5279-5291
+        const double a1 = fks - fk;
+        const double a2 = (fks + fk) / (a1 + fhs);
+        const double rk = 2.0 / (fk + 1.0);
+        const cplx pt = p2;
+        p2 = cscale(csub(cmul(p2, cmake((fk + xx) * rk, yy * rk)), p1), a2);
+        p1 = pt;
+        cs = cadd(cs, p2);
+        fks = a1 - fk + 1.0;
+        fk = fk - 1.0;
+    }
+    cplx pt = cmake(1.0 / hypot(cs.re, cs.im), 0.0);
+    s1 = cmul(pt, p2);
+    cs = cmul(cmake(cs.re, -cs.im), pt);
+    s1 = cmul(cmul(coef, s1), cs);
+    pt = cmake(1.0 / hypot(p2.re, p2.im), 0.0);
+    p1 = cmul(pt, p1);
+    p2 = cmul(cmake(p2.re, -p2.im), pt);
+    pt = cmul(p1, p2);
+    s2 = cmul(s1, cadd(cmake(1.0, 0.0), cdiv(csub(cmake(0.5, 0.0), pt), z)));
+    out.k0 = s1;
+    out.k1 = s2;
+    return out;
+}
+
+// A0(p) of the Hantush-with-storage solution (laplace_hankel_solutions.f90:255-267), per lane
+UCF_DEV cplx hstorage_A0(const ucf_dev_params& P, cplx p)
+{
+    const cplx xi = rscale(P.hs_rDw, csqrt_(p));                                                // :255
+    const k01 K = cbesk01_(xi);                                                                 // :258-265
+    return rdiv(2.0, cadd(cmul(cscale(p, P.hs_CDw), K.k0), cmul(xi, K.k1)));                    // :267
+}
+
 // ------------------------------------------- laplace_hankel_solutions.f90:30-120
 // z-independent part of one (a,p) sample
 struct sample_common {
@@ -85,6 +229,7 @@ struct sample_common {
     cplx den;       // water-table closure denominator                    (:86-87 or :90-91)
     cplx mn_pre, mn_uod;   // Mishra/Neuman-Malama: 2/(kappa*etasq), u/Delta0  (:437-439)
     cplx fd_s1;     // Mishra/Neuman FD: sigma(1) = A1                     (:517-523)
+    cplx hs_pre;    // Hantush+storage: uDf/bD                             (:268,299)
     bool small_eta; // Re(eta) < MAXEXP                                   (:84)
     bool fd_use;    // |sigma1| > tiny                                    (:521)
 };
@@ -108,12 +253,25 @@ UCF_DEV cplx hantush_z(const ucf_dev_params& P, const sample_common& S, double z
     return cdivr(cmul(udp, S.th), P.bD);                                                        // :200
 }
 
-template <int FAMILY>   // 0 Theis, 1 Hantush, 2 water-table (models 3,4,5), 3 MN-Malama, 4 MN-FD
+template <int FAMILY>   // 0 Theis, 1 Hantush, 2 water-table (models 3,4,5), 3 MN-Malama, 4 MN-FD, 5 Hantush+storage
 UCF_DEV void sample_prepare(const ucf_dev_params& P, double a, cplx p, bool need_lay1, sample_common& S,
-                            lds_c* fdbuf, int lane)
+                            lds_c* fdbuf, int lane, cplx lane_aux)
 {
     const double a2 = a * a;
     const cplx q = caddr(p, a2);
+    if (FAMILY == 5) {                                                                          // :204-301
+        // lane_aux = A0(p);  uDf = A0/((p+a^2)(p*tDb+1)) (:268);  u = (uDf/bD)*uDp (:299)
+        const cplx uDf = cdiv(lane_aux, cmul(q, caddr(cscale(p, P.hs_tDb), 1.0)));
+        S.hs_pre = cdivr(uDf, P.bD);
+        S.eta = csqrt_(cdivr(q, P.kappa));
+        S.ff1 = csinh_(cscale(S.eta, P.dD));
+        S.ff2 = csinh_(cscale(S.eta, P.lD1));
+        S.she = csinh_(S.eta);
+        if (need_lay1)
+            S.g3 = csub(cexp_(cneg(cscale(S.eta, P.lD1))),
+                        cdiv(cadd(S.ff1, cmul(cexp_(cneg(S.eta)), S.ff2)), S.she));             // :284-287
+        return;
+    }
     S.th = rdiv(2.0, q);
     if (FAMILY == 0) return;
     if (FAMILY == 3) {                                                                          // :404-442
@@ -186,6 +344,22 @@ UCF_DEV void sample_prepare(const ucf_dev_params& P, double a, cplx p, bool need
         const cplx a2v = cmul(cmake(invhsq, 0.0), S.che);                                       // :508-509
         const cplx v1 = cmul(cneg(cc), S.top);                                                  // :514
         const cplx v2 = rscale(-invhsq, S.top);                                                 // :513
+#if UCF_FAST
+        // fast flavour: only x(1) is needed (:521-523) and v(3:n) = 0, so eliminate from the bottom up --
+        // a continued fraction B_i = b_i - c_i a_{i+1} / B_{i+1} with nothing to store (same system,
+        // exact arithmetic gives the same x(1) as the forward Thomas sweep of utility.f90:96-135)
+        (void)fdbuf; (void)lane;
+        const double K = csup * invhsq;
+        cplx Bn = csubr(caddr(rsub(b3h - 2.0 * invhsq, caddr(cscale(B1, P.fd_e[n - 1]), B2)), invhsq), b3h);   // b(n), :501-502
+        for (int i = n - 1; i >= 2; i--) {
+            const cplx bi = rsub(b3h - 2.0 * invhsq, caddr(cscale(B1, P.fd_e[i - 1]), B2));
+            Bn = csub(bi, rscale(K, cinv_plain_(Bn)));
+        }
+        const cplx iB2 = cinv_plain_(Bn);                               // 1/B_2
+        const cplx B1p = csub(b1, cmul(rscale(csup, a2v), iB2));        // B_1 = b_1 - c_1 a_2 / B_2
+        const cplx v1p = csub(v1, cmul(rscale(csup, iB2), v2));         // v'_1 = v_1 - (c_1/B_2) v_2
+        cplx x = cdiv(v1p, B1p);
+#else
         // forward sweep
         cplx bp = b1, vp = v1;
         lds_st(fdbuf, 0, lane, bp);
@@ -208,6 +382,7 @@ UCF_DEV void sample_prepare(const ucf_dev_params& P, double a, cplx p, bool need
             cplx vpi = lds_ld(fdbuf, n + i - 1, lane);
             x = cdiv(csub(vpi, cmul(cmake(csup, 0.0), x)), bpi);
         }
+#endif
         S.fd_s1 = x;
         S.fd_use = cabs_(x) > UCF_DBL_MIN;                                                      // :521
     }
@@ -223,6 +398,16 @@ UCF_DEV cplx sample_z(const ucf_dev_params& P, const sample_common& S, int iz)
         return cmul(S.mn_pre, radd(1.0, cmul(S.mn_uod, ccosh_(cscale(S.eta, zD)))));            // :437-439
     }
     const cplx chz = ccosh_(cscale(S.eta, zD));
+    if (FAMILY == 5) {
+        cplx uDp;
+        if (lay == 1) {
+            uDp = cmul(S.g3, chz);                                                              // :293
+        } else {
+            const cplx g2 = cdiv(cadd(cmul(S.ff1, chz), cmul(S.ff2, ccosh_(cscale(S.eta, 1.0 - zD)))), S.she);   // :278-282
+            uDp = (lay == 2) ? rsub(1.0, g2) : csub(ccosh_(cscale(S.eta, P.dD1 - zD)), g2);    // :296 / :290
+        }
+        return cmul(S.hs_pre, uDp);                                                             // :299
+    }
     if (FAMILY == 1) return hantush_z(P, S, zD, lay, chz);
     if (FAMILY == 2) {
         const cplx u = (P.model == 4) ? S.th : hantush_z(P, S, zD, lay, chz);
@@ -465,6 +650,7 @@ point_kernel(const ucf_dev_params P, int npts, int per_point, int nr, int nsv, i
 #if UCF_FAST
         const lane_consts LC = make_lane_consts(P, p, lt);
 #endif
+        const cplx lane_aux = (FAMILY == 5) ? hstorage_A0(P, p) : cmake(0.0, 0.0);
 
         for (int s = 0; s < (R + nacc) * nz; s++) lds_st(lds, s, lane, cmake(0.0, 0.0));
 
@@ -502,7 +688,7 @@ point_kernel(const ucf_dev_params P, int npts, int per_point, int nr, int nsv, i
                 }
             };
 #if UCF_FAST
-            if (FAMILY == 1 || FAMILY == 2) {
+            if (FAMILY == 1 || FAMILY == 2 || FAMILY == 4) {
                 fast_common F;
                 const bool ok = fast_prepare<FAMILY>(P, LC, a, need_lay1, F);
                 if (__all(ok)) {
@@ -512,7 +698,7 @@ point_kernel(const ucf_dev_params P, int npts, int per_point, int nr, int nsv, i
             }
 #endif
             sample_common S;
-            sample_prepare<FAMILY>(P, a, p, need_lay1, S, fdbuf, lane);
+            sample_prepare<FAMILY>(P, a, p, need_lay1, S, fdbuf, lane, lane_aux);
             for (int z = 0; z < nz; z++) accumulate(z, sample_z<FAMILY>(P, S, z));
         }
         // ---- per depth: Richardson, Wynn-epsilon, de Hoog (:159-230)
@@ -572,16 +758,17 @@ samples_kernel(const ucf_dev_params P, int n_a, const double* __restrict__ av, d
     bool fast = false;
 #if UCF_FAST
     fast_common F;
-    if (FAMILY == 1 || FAMILY == 2) {
+    if (FAMILY == 1 || FAMILY == 2 || FAMILY == 4) {
         const lane_consts LC = make_lane_consts(P, p, lt);
         fast = __all(fast_prepare<FAMILY>(P, LC, a, need_lay1, F));
     }
 #endif
-    if (!fast) sample_prepare<FAMILY>(P, a, p, need_lay1, S, lds, lane);
+    const cplx lane_aux = (FAMILY == 5) ? hstorage_A0(P, p) : cmake(0.0, 0.0);
+    if (!fast) sample_prepare<FAMILY>(P, a, p, need_lay1, S, lds, lane, lane_aux);
     for (int z = 0; z < P.nz; z++) {
         cplx f;
 #if UCF_FAST
-        if (fast) f = fast_sample_z<(FAMILY == 1 || FAMILY == 2) ? FAMILY : 1>(P, F, z);
+        if (fast) f = fast_sample_z<(FAMILY == 1 || FAMILY == 2 || FAMILY == 4) ? FAMILY : 1>(P, F, z);
         else
 #endif
             f = sample_z<FAMILY>(P, S, z);
@@ -595,6 +782,16 @@ samples_kernel(const ucf_dev_params P, int n_a, const double* __restrict__ av, d
 }
 
 #if !UCF_FAST
+__global__ void __launch_bounds__(UCF_WAVE)
+bessel_kernel(int n, const double* __restrict__ z, double* __restrict__ k, int* __restrict__ ierr)
+{
+    const int i = blockIdx.x * UCF_WAVE + threadIdx.x;
+    if (i >= n) return;
+    const k01 r = cbesk01_(cmake(z[2 * i], z[2 * i + 1]));
+    k[4 * i] = r.k0.re; k[4 * i + 1] = r.k0.im; k[4 * i + 2] = r.k1.re; k[4 * i + 3] = r.k1.im;
+    ierr[i] = r.ierr;
+}
+
 __global__ void __launch_bounds__(UCF_WAVE)
 dehoog_kernel(int n, int M, double alpha, double logtol, const double* __restrict__ t, const double* __restrict__ tee,
               const double* __restrict__ fp, double* __restrict__ ft)
@@ -658,6 +855,7 @@ static inline int family_of(const ucf_dev_params& dp)
     switch (dp.model) {
     case 0: return 0;
     case 1: return 1;
+    case 2: return 5;
     case 3: case 4: case 5: return 2;
     case 6: return dp.MNtype == 1 ? 3 : (dp.MNtype == 2 ? 4 : -1);
     default: return -1;
@@ -667,7 +865,9 @@ static inline int family_of(const ucf_dev_params& dp)
 static inline size_t point_lds_bytes(const ucf_dev_params& dp)
 {
     size_t bytes = ((size_t)(dp.R + dp.nacc) * dp.nz * UCF_WAVE + (size_t)(dp.nacc > dp.R ? dp.nacc : dp.R) * (UCF_WAVE / 2)) * sizeof(lds_c);
+#if !UCF_FAST
     if (family_of(dp) == 4) bytes += 2 * (size_t)dp.order * UCF_WAVE * sizeof(lds_c);
+#endif
     return bytes;
 }
 
@@ -707,6 +907,7 @@ int launch_points(const ucf_dev_params& dp, int npts, int per_point, int nr, int
     case 2: UCF_LAUNCH(2); break;
     case 3: UCF_LAUNCH(3); break;
     case 4: UCF_LAUNCH(4); break;
+    case 5: UCF_LAUNCH(5); break;
     }
 #undef UCF_LAUNCH
     return hipGetLastError() == hipSuccess ? UCF_OK : UCF_ERR_HIP;
@@ -718,7 +919,7 @@ int launch_samples(const ucf_dev_params& dp, int n_a, const double* d_a, double 
     const int fam = family_of(dp);
     if (fam < 0) return UCF_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
-    size_t lds = (fam == 4) ? 2 * (size_t)dp.order * UCF_WAVE * sizeof(lds_c) : 16;
+    size_t lds = (fam == 4 && !UCF_FAST) ? 2 * (size_t)dp.order * UCF_WAVE * sizeof(lds_c) : 16;
     dim3 grid(n_a), block(UCF_WAVE);
 #define UCF_LAUNCH(F)                                                                                          \
     do {                                                                                                       \
@@ -732,12 +933,18 @@ int launch_samples(const ucf_dev_params& dp, int n_a, const double* d_a, double 
     case 2: UCF_LAUNCH(2); break;
     case 3: UCF_LAUNCH(3); break;
     case 4: UCF_LAUNCH(4); break;
+    case 5: UCF_LAUNCH(5); break;
     }
 #undef UCF_LAUNCH
     return hipGetLastError() == hipSuccess ? UCF_OK : UCF_ERR_HIP;
 }
 
 #if !UCF_FAST
+int launch_bessel(int n, const double* d_z, double* d_k, int* d_ierr, void* stream)
+{
+    hipLaunchKernelGGL(bessel_kernel, dim3((n + UCF_WAVE - 1) / UCF_WAVE), dim3(UCF_WAVE), 0, (hipStream_t)stream, n, d_z, d_k, d_ierr);
+    return hipGetLastError() == hipSuccess ? UCF_OK : UCF_ERR_HIP;
+}
 int launch_dehoog(int n, int M, double alpha, double logtol, const double* d_t, const double* d_tee,
                   const double* d_fp, double* d_ft, void* stream)
 {

@@ -93,6 +93,7 @@ UCF_DEV cplx cinv_scaled(cplx z)
 
 struct lane_consts {     // per lane, constant over the abscissa loop of one point
     cplx p, lt, xifac;   // xifac = alphaD/p [* MoenchM / sum_m 1/(1+p/gamma_m)]   (:70,72-75)
+    cplx fdB1;           // FD: p*beta0*exp(-beta2)/kappa                          (:492)
 };
 
 UCF_DEV lane_consts make_lane_consts(const ucf_dev_params& P, cplx p, cplx lt)
@@ -107,12 +108,14 @@ UCF_DEV lane_consts make_lane_consts(const ucf_dev_params& P, cplx p, cplx lt)
         xf = cmul(cscale(xf, (double)P.MoenchM), cinv_plain(sum));
     }
     L.xifac = xf;
+    L.fdB1 = cscale(cscale(cscale(p, P.fd_beta0), P.fd_expmb2), P.inv_kappa);
     return L;
 }
 
 struct fast_common {
     cplx th, eta, ff1, ff2, inv_she, she, che, top, g3, inv_den, ex1;   // ex1 = exp(-eta)
-    bool small_eta;
+    cplx fd_s1;          // FD: sigma(1)
+    bool small_eta, fd_use;
 };
 
 // z-independent part.  Returns false (for this lane) if the fast evaluation is not applicable.
@@ -171,6 +174,31 @@ UCF_DEV bool fast_prepare(const ucf_dev_params& P, const lane_consts& L, double 
         if (S.small_eta) S.inv_den = cinv_scaled(cadd(cmul(one_bex, S.che), cmul(xi, S.she)));  // :86-87
         else S.inv_den = cinv_scaled(cadd(one_bex, xi));                                        // :90-91
     }
+    if (FAMILY == 4) {
+        // Mishra/Neuman finite-difference vadose zone (:444-544): sigma(1) of the tridiagonal system by
+        // elimination from the bottom up (continued fraction; v(3:n) = 0 and only x(1) is used, :521-523)
+        const int n = P.order;
+        const double h = P.fd_h, invhsq = P.fd_invhsq, b3h = P.fd_beta3 / h;
+        const double B2 = a2 * P.inv_kappa;                                                     // :493
+        const double csup = invhsq - b3h, K = csup * invhsq, bmid = b3h - 2.0 * invhsq - B2;
+        const cplx B1 = L.fdB1;
+        const cplx cc = cmake((b3h - invhsq - B2) - B1.re * P.fd_e[0], -(B1.im * P.fd_e[0]));   // :495,498
+        const cplx eoh = cscale(S.eta, 1.0 / h);
+        const cplx b1 = csub(cmul(cc, S.che), cmul(eoh, S.she));                                // :499-500
+        cplx Bn = cmake((bmid + invhsq - b3h) - B1.re * P.fd_e[n - 1], -(B1.im * P.fd_e[n - 1]));   // :501-502
+        for (int i = n - 1; i >= 2; i--) {
+            const double e = P.fd_e[i - 1];
+            const double r = K * fast_rcp(Bn.re * Bn.re + Bn.im * Bn.im);
+            Bn = cmake(__builtin_fma(-B1.re, e, bmid) - Bn.re * r, __builtin_fma(-B1.im, e, Bn.im * r));
+        }
+        const cplx iB2 = cinv_plain(Bn);
+        const cplx a2v = cscale(S.che, invhsq);                                                 // :508-509
+        const cplx B1p = csub(b1, cmul(rscale(csup, a2v), iB2));
+        const cplx v1 = cneg(cmul(cc, S.top)), v2 = rscale(-invhsq, S.top);                     // :513-514
+        const cplx v1p = csub(v1, cmul(rscale(csup, iB2), v2));
+        S.fd_s1 = cmul(v1p, cinv_scaled(B1p));
+        S.fd_use = (fabs(S.fd_s1.re) + fabs(S.fd_s1.im)) > 2.3e-308;                            // :521
+    }
     return true;
 }
 
@@ -216,6 +244,10 @@ UCF_DEV cplx fast_sample_z(const ucf_dev_params& P, const fast_common& S, int iz
     const int lay = P.zLay[iz];
     cplx chz, exz = cmake(0.0, 0.0);
     if (FAMILY == 1) return fast_hantush_z<1>(P, S, zD, lay, &chz, &exz);
+    if (FAMILY == 4) {
+        const cplx sH = fast_hantush_z<4>(P, S, zD, lay, &chz, &exz);
+        return S.fd_use ? cadd(sH, cmul(S.fd_s1, chz)) : sH;                                    // :522-525
+    }
     cplx u;
     if (P.model == 4) {
         u = S.th;

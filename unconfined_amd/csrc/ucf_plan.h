@@ -20,6 +20,8 @@ struct ucf_dev_params {
     // fast flavour: hoisted reciprocals, plan-level exact folds, validity bound of the fast evaluation
     double inv_kappa, inv_bD, fast_eta_max;
     int fold_dD, fold_lD1, share_g1top, _pad2;
+    // Hantush with wellbore storage (:204-301): rDw, CDw (:250), tDb (:253)
+    double hs_rDw, hs_CDw, hs_tDb;
     // Mishra/Neuman (Malama form, :404-442): host-evaluated scalar prefactors
     double mn_vartheta, mn_u0;
     // Mishra/Neuman FD (:444-544)
@@ -65,6 +67,7 @@ int launch_points(const ucf_dev_params& dp, int npts, int per_point, int nr, int
                   ucf_stats* d_stats, void* stream);
 int launch_samples(const ucf_dev_params& dp, int n_a, const double* d_a, double rD, const double* d_p, double* d_fp,
                    void* stream);
+int launch_bessel(int n, const double* d_z, double* d_k, int* d_ierr, void* stream);
 int launch_dehoog(int n, int M, double alpha, double logtol, const double* d_t, const double* d_tee,
                   const double* d_fp, double* d_ft, void* stream);
 int launch_wynn(int n, int nterms, const double* d_series, double* d_acc, int* d_status, void* stream);

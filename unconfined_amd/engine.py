@@ -189,6 +189,17 @@ def extraptozero(x, y):
     return out
 
 
+def bessel_k01(z):
+    """z[n,2] -> (K[n,2,2] = (K0,K1), ierr[n]); Amos cbesk(fnu=0, n=2, kode=1) on the device"""
+    lib = _libmod.load()
+    z = _f64(z)
+    n = z.shape[0]
+    k = np.zeros((n, 2, 2))
+    ierr = np.zeros(n, np.int32)
+    _libmod.check(lib.ucf_bessel_k01(n, z, k, ierr))
+    return k, ierr
+
+
 def fp64_fma_peak() -> float:
     lib = _libmod.load()
     v = C.c_double(0.0)

@@ -27,7 +27,7 @@ EXPORTS = [
     "ucf_logspace", "ucf_linspace", "ucf_zlay", "ucf_split_vector",
     "ucf_drawdown_batch", "ucf_drawdown_batch_device", "ucf_drawdown_grid", "ucf_drawdown_grid_device",
     "ucf_screen_average",
-    "ucf_eval_samples", "ucf_pvalues", "ucf_dehoog", "ucf_wynn_epsilon", "ucf_extraptozero",
+    "ucf_eval_samples", "ucf_pvalues", "ucf_dehoog", "ucf_wynn_epsilon", "ucf_extraptozero", "ucf_bessel_k01",
     "ucf_fp64_fma_peak",
 ]
 
@@ -88,6 +88,7 @@ def load() -> C.CDLL:
     lib.ucf_dehoog.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, _dp, _dp, _dp, _dp]
     lib.ucf_wynn_epsilon.argtypes = [C.c_int, C.c_int, _dp, _dp, _ip]
     lib.ucf_extraptozero.argtypes = [C.c_int, C.c_int, _dp, _dp, _dp]
+    lib.ucf_bessel_k01.argtypes = [C.c_int, _dp, _dp, _ip]
     lib.ucf_fp64_fma_peak.argtypes = [C.POINTER(C.c_double)]
     _lib = lib
     return lib
