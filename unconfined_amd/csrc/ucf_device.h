@@ -656,50 +656,52 @@ point_kernel(const ucf_dev_params P, int npts, int per_point, int nr, int nsv, i
 
         // one pass over all abscissae: n < N tanh-sinh on [0,arg] feeding every Richardson level
         // (driver.f90:129-157); n >= N Gauss-Lobatto between successive J0 zeros (:187-203)
-        for (int n = 0; n < nabs; n++) {
-            const double2 aa = row[n];
-            const double a = aa.x, aj = aa.y;
-            const bool ts = n < N;
-            const int g = ts ? 0 : (n - N);
-            const int jj = g / ngl, m = g - jj * ngl;
-            // val = a*J0(a rD) * f(a,p,z) * lapTime(p)  (lhs.f90:118), accumulated into the level sums /
-            // the current interval's area
-            auto accumulate = [&](int z, cplx f) {
-                const cplx val = cmul(rscale(aj, f), lt);
-                if (ts) {
-                    const int n1 = n + 1;
-                    for (int j = 1; j <= R; j++) {
-                        const int sh = R - j;
-                        if ((n1 & ((1 << sh) - 1)) == 0) {                                      // driver.f90:150
-                            const double w = P.ts_w[(size_t)(j - 1) * N + ((n1 >> sh) - 1)];
-                            const int slot = (j - 1) * nz + z;
-                            lds_st(accTS, slot, lane, cadd(lds_ld(accTS, slot, lane), rscale(w, val)));
-                        }
+        // val = a*J0(a rD) * f(a,p,z) * lapTime(p)  (lhs.f90:118), accumulated into the level sums /
+        // the current interval's area
+        auto accumulate = [&](int n, double aj, int z, cplx f) {
+            const cplx val = cmul(rscale(aj, f), lt);
+            if (n < N) {
+                const int n1 = n + 1;
+                for (int j = 1; j <= R; j++) {
+                    const int sh = R - j;
+                    if ((n1 & ((1 << sh) - 1)) == 0) {                                          // driver.f90:150
+                        const double w = P.ts_w[(size_t)(j - 1) * N + ((n1 >> sh) - 1)];
+                        const int slot = (j - 1) * nz + z;
+                        lds_st(accTS, slot, lane, cadd(lds_ld(accTS, slot, lane), rscale(w, val)));
                     }
-                } else {
-                    const int slot = jj * nz + z;
-                    cplx acc = cadd(lds_ld(accGL, slot, lane), cscale(val, P.gl_w[m]));         // :201-202
-                    if (m == ngl - 1) {
-                        const double lob = P.j0z[sv + jj - 1] / rD;
-                        const double hib = P.j0z[sv + jj] / rD;
-                        acc = rscale((hib - lob) / 2.0, acc);
-                    }
-                    lds_st(accGL, slot, lane, acc);
                 }
-            };
-#if UCF_FAST
-            if (FAMILY == 1 || FAMILY == 2 || FAMILY == 4) {
-                fast_common F;
-                const bool ok = fast_prepare<FAMILY>(P, LC, a, need_lay1, F);
-                if (__all(ok)) {
-                    for (int z = 0; z < nz; z++) accumulate(z, fast_sample_z<FAMILY>(P, F, z));
-                    continue;
+            } else {
+                const int g = n - N;
+                const int jj = g / ngl, m = g - jj * ngl;
+                const int slot = jj * nz + z;
+                cplx acc = cadd(lds_ld(accGL, slot, lane), cscale(val, P.gl_w[m]));             // :201-202
+                if (m == ngl - 1) {
+                    const double lob = P.j0z[sv + jj - 1] / rD;
+                    const double hib = P.j0z[sv + jj] / rD;
+                    acc = rscale((hib - lob) / 2.0, acc);
                 }
+                lds_st(accGL, slot, lane, acc);
             }
+        };
+        int n = 0;
+#if UCF_FAST
+        // abscissae increase monotonically (tanh-sinh on [0,arg], then the J0 intervals), so does Re(eta):
+        // the fast evaluation is valid for a leading run of abscissae; the generic evaluator finishes the rest
+        if (FAMILY == 1 || FAMILY == 2 || FAMILY == 4) {
+            for (; n < nabs; n++) {
+                const double2 aa = row[n];
+                fast_common F;
+                const bool ok = fast_prepare<FAMILY>(P, LC, aa.x, need_lay1, F);
+                if (!__all(ok)) break;
+                for (int z = 0; z < nz; z++) accumulate(n, aa.y, z, fast_sample_z<FAMILY>(P, F, z));
+            }
+        }
 #endif
+        for (; n < nabs; n++) {
+            const double2 aa = row[n];
             sample_common S;
-            sample_prepare<FAMILY>(P, a, p, need_lay1, S, fdbuf, lane, lane_aux);
-            for (int z = 0; z < nz; z++) accumulate(z, sample_z<FAMILY>(P, S, z));
+            sample_prepare<FAMILY>(P, aa.x, p, need_lay1, S, fdbuf, lane, lane_aux);
+            for (int z = 0; z < nz; z++) accumulate(n, aa.y, z, sample_z<FAMILY>(P, S, z));
         }
         // ---- per depth: Richardson, Wynn-epsilon, de Hoog (:159-230)
         for (int z = 0; z < nz; z++) {
