@@ -34,6 +34,7 @@ extern "C" {
 #define UCF_VERSION 100        /* 0.1.0 */
 #define UCF_MAX_MOENCH 16      /* max number of Moench alphas (driver_io.f90:142-151) */
 #define UCF_MAX_NZ 32          /* max depths per point handled by one launch */
+#define UCF_MAX_SCHEDULE 100    /* steps of a piecewise-constant pumping schedule (time.f90:81-95) */
 #define UCF_MAX_LAP_M 31       /* 2M+1 <= 64: one Laplace sample per lane of a wave */
 
 typedef enum ucf_status {
@@ -65,7 +66,8 @@ typedef struct ucf_params {
     int model;            /* 0 Theis, 1 Hantush, 2 Hantush+storage, 3 Moench, 4 Malama full, 5 Malama partial, 6 Mishra/Neuman */
     int MNtype;           /* model 6: 0 naive (ARB, unsupported), 1 Malama, 2 finite difference */
     int order;            /* model 6 / MNtype 2: FD nodes in the vadose zone */
-    int timeType;         /* pumping-rate time behaviour (time.f90:46); this build: 1..6,8 */
+    int timeType;         /* pumping-rate time behaviour (time.f90:46): 1..8, or -n = n-step piecewise-constant
+                             schedule (-1..-100) whose 2n+1 parameters are in timeParExt */
     double timePar[2];
     double Q;             /* pumping rate [L^3/T] */
     double l, d;          /* depth to screen bottom / top from aquifer top [L] */
@@ -88,6 +90,8 @@ typedef struct ucf_params {
     int _pad1;
     double alpha, tol;    /* de Hoog abscissa of convergence, tolerance */
     double rwobs, sF;     /* observation well radius / shape factor (model 2) */
+    /* timeType = -n: tpar(1:n) step start times, tpar(n+1) final time, tpar(n+2:2n+1) rates (types.f90:66-70) */
+    double timeParExt[2 * UCF_MAX_SCHEDULE + 1];
 } ucf_params;
 
 /* Derived, dimensionless quantities (driver_io.f90:531-567) -- read back for tests/headers. */
@@ -131,6 +135,11 @@ int ucf_plan_gauss_lobatto(const ucf_plan* plan, int n, double* x, double* w);
 /* execution mode: 0 = faithful (reference operation order, no FMA contraction),
  *                 1 = fast (same algorithm, FMA contraction + shared subexpressions). */
 int ucf_plan_set_mode(ucf_plan* plan, int mode);
+
+/* measurement: when enabled, the dominant kernel of every following grid call is bracketed by HIP
+ * events on its stream; ucf_plan_kernel_ms waits for the last bracket and returns its duration and name. */
+int ucf_plan_set_timing(ucf_plan* plan, int enable);
+int ucf_plan_kernel_ms(ucf_plan* plan, double* ms, const char** kernel_name);
 
 /* ---- host-side helpers that the reference computes in read_input ---- */
 int ucf_logspace(int lo, int hi, int n, double* out);                   /* utility.f90:51-57 */

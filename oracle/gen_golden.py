@@ -122,6 +122,9 @@ DECKSET = {
     "theis_stairs": (mk(SMALL, model=0, l=7.5, d=2.5, timeType=4, timePar=[100.0, 1000.0]), TimeSpec(True, -1, 6, 40), [None]),
     "theis_square": (mk(SMALL, model=0, l=7.5, d=2.5, timeType=5, timePar=[100.0, 10.0]), TimeSpec(True, -1, 6, 40), [None]),
     "theis_cos": (mk(SMALL, model=0, l=7.5, d=2.5, timeType=6, timePar=[0.01, 10.0]), TimeSpec(True, -1, 6, 40), [None]),
+    "theis_sched3": (mk(SMALL, model=0, l=7.5, d=2.5, timeType=-3, timePar=[0.0, 100.0, 1000.0, 5000.0, 1.0, 0.5, 2.0]),
+                     TimeSpec(True, -1, 6, 40), [None]),
+    "neuman_sched2": (mk(CAPE, timeType=-2, timePar=[0.0, 10.0, 500.0, 1.0, 0.25]), TimeSpec(True, -1, 8, 40), [None]),
     "theis_sqwave": (mk(SMALL, model=0, l=7.5, d=2.5, timeType=8, timePar=[100.0, 10.0]), TimeSpec(True, -1, 6, 40), [None]),
 }
 
@@ -375,7 +378,7 @@ def run_generic_stages(workdir, flavour="O2"):
 # ------------------------------------------------------------------ end-to-end
 def parse_out(path):
     rows = []
-    with open(path) as f:
+    with open(path, errors="replace") as f:     # the reference's header may carry raw bytes
         for ln in f:
             if ln.startswith("#") or not ln.strip():
                 continue

@@ -708,6 +708,7 @@ int ucfo_cbesk01(double zr, double zi, double* k_re_im /* K0re,K0im,K1re,K1im */
 typedef struct {
     int model, MNtype, order, timeType, MoenchM;
     R timePar[2];
+    R sched_t[UCF_MAX_SCHEDULE], sched_dq[UCF_MAX_SCHEDULE], sched_tf, sched_sum;   /* time.f90:81-95 */
     R kappa, alphaD, beta, lD, dD, bD;
     R MoenchGamma[UCF_MAX_MOENCH];
     R Sy, Ss, b, ak, ac, psia, psik, b1, akD, lambdaD, usLD;
@@ -720,6 +721,19 @@ static void mdl_fill(mdl* m, const ucf_params* P, const ucf_derived* D)
     m->model = P->model; m->MNtype = P->MNtype; m->order = P->order;
     m->timeType = P->timeType; m->MoenchM = P->MoenchM;
     m->timePar[0] = (R)P->timePar[0]; m->timePar[1] = (R)P->timePar[1];
+    if (P->timeType < 0 && P->timeType >= -UCF_MAX_SCHEDULE) {         /* time.f90:83-89 */
+        const int n = -P->timeType;
+        double qprev = 0.0, sum = 0.0;
+        for (int k = 0; k < n; k++) {
+            const double dq = P->timeParExt[n + 1 + k] - qprev;
+            qprev = P->timeParExt[n + 1 + k];
+            m->sched_t[k] = (R)P->timeParExt[k];
+            m->sched_dq[k] = (R)dq;
+            sum = (k == 0) ? dq : sum + dq;
+        }
+        m->sched_tf = (R)P->timeParExt[n];
+        m->sched_sum = (R)sum;
+    }
     m->kappa = (R)P->kappa; m->alphaD = (R)D->alphaD; m->beta = (R)P->beta;
     m->lD = (R)D->lD; m->dD = (R)D->dD; m->bD = (R)D->bD;
     for (int i = 0; i < UCF_MAX_MOENCH; i++) m->MoenchGamma[i] = (R)D->MoenchGamma[i];
@@ -734,6 +748,15 @@ static void mdl_fill(mdl* m, const ucf_params* P, const ucf_derived* D)
 static C lap_time(const mdl* m, C p)
 {
     const R t1 = m->timePar[0], t2 = m->timePar[1];
+    if (m->timeType < 0 && m->timeType >= -UCF_MAX_SCHEDULE) {           /* :81-95 piecewise-constant rate */
+        const int n = -m->timeType;
+        C sum = c_make(RC(0.0), RC(0.0));
+        for (int k = 0; k < n; k++) {
+            C term = c_rscale(m->sched_dq[k], c_exp(c_rscale(-m->sched_t[k], p)));
+            sum = (k == 0) ? term : c_add(sum, term);
+        }
+        return c_div(c_sub(sum, c_rscale(m->sched_sum, c_exp(c_rscale(-m->sched_tf, p)))), p);
+    }
     switch (m->timeType) {
     case 1: return c_div(c_exp(c_scale(p, -t1)), p);                                       /* :47-49 */
     case 2: return c_sub(c_div(c_exp(c_scale(p, -t1)), p), c_div(c_exp(c_scale(p, -t2)), p)); /* :50-52 */

@@ -7,6 +7,7 @@ import ctypes as C
 UCF_MAX_MOENCH = 16
 UCF_MAX_NZ = 32
 UCF_MAX_LAP_M = 31
+UCF_MAX_SCHEDULE = 100
 
 
 class UcfParams(C.Structure):
@@ -23,6 +24,7 @@ class UcfParams(C.Structure):
         ("j0s", C.c_int * 2), ("_pad1", C.c_int),
         ("alpha", C.c_double), ("tol", C.c_double),
         ("rwobs", C.c_double), ("sF", C.c_double),
+        ("timeParExt", C.c_double * (2 * UCF_MAX_SCHEDULE + 1)),
     ]
 
 
@@ -50,6 +52,9 @@ def params_from_deck(dk) -> UcfParams:
     P.model, P.MNtype, P.order, P.timeType = dk.model, dk.MNtype, dk.order, dk.timeType
     tp = list(dk.timePar) + [0.0, 0.0]
     P.timePar[0], P.timePar[1] = tp[0], tp[1]
+    if dk.timeType < 0:
+        for i, v in enumerate(dk.timePar[:2 * UCF_MAX_SCHEDULE + 1]):
+            P.timeParExt[i] = v
     for n in ("Q", "l", "d", "rw", "rc", "gammaSkin", "b", "Kr", "kappa", "Ss", "Sy", "beta",
               "ac", "ak", "psia", "psik", "usL", "alpha", "tol", "rwobs", "sF"):
         setattr(P, n, float(getattr(dk, n)))

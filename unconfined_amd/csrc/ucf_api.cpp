@@ -87,7 +87,9 @@ int validate(const ucf_params& P)
     if (P.ord < 3) return fail(UCF_ERR_GAUSS_LOBATTO, "Gauss-Lobatto order must be >= 3");
     if (P.model == 2 && (P.rwobs <= 0.0 || P.sF <= 0.0))
         return fail(UCF_ERR_OBSERVATION, "model 2 needs a positive observation-well radius and shape factor");   // driver_io.f90:374-383
-    if (P.timeType < 1 || P.timeType > 8) return fail(UCF_ERR_UNSUPPORTED, "time behaviour %d is not built (1..8 are)", P.timeType);
+    if (P.timeType <= -101) return fail(UCF_ERR_UNSUPPORTED, "piecewise-linear pumping schedules (time behaviour <= -101) index out of bounds in the reference (time.f90:101,115) and are not built");
+    if (P.timeType < -UCF_MAX_SCHEDULE || P.timeType == 0 || P.timeType > 8) return fail(UCF_ERR_UNSUPPORTED, "time behaviour %d does not exist (1..8, -1..-99 do)", P.timeType);
+    if (P.timeType == -100) return fail(UCF_ERR_UNSUPPORTED, "time behaviour -100: the reference allocates a single parameter for it (driver_io.f90:124)");
     return UCF_OK;
 }
 
@@ -300,8 +302,24 @@ int ucf_plan_create(const ucf_params* Pin, ucf_plan** out)
         dp.mn_u0 = beta0 / 2.0;
     }
 
+    // piecewise-constant pumping schedule (time.f90:81-95): increments and their sum, once
+    std::vector<double> sched;
+    if (P.timeType < 0) {
+        const int n = -P.timeType;
+        sched.resize(2 * n + 2);
+        double qprev = 0.0, sum = 0.0;
+        for (int k = 0; k < n; k++) {
+            const double dq = P.timeParExt[n + 1 + k] - qprev;
+            qprev = P.timeParExt[n + 1 + k];
+            sched[k] = P.timeParExt[k];
+            sched[n + k] = dq;
+            sum = (k == 0) ? dq : sum + dq;
+        }
+        sched[2 * n] = P.timeParExt[n];
+        sched[2 * n + 1] = sum;
+    }
     // one device allocation for all tables
-    const size_t n_tab = (size_t)N + (size_t)R * N + 2 * (size_t)ngl + D.nj0z + fd_e.size();
+    const size_t n_tab = (size_t)N + (size_t)R * N + 2 * (size_t)ngl + D.nj0z + fd_e.size() + sched.size();
     std::vector<double> host(n_tab);
     size_t o = 0;
     const size_t o_tsx = o; std::memcpy(&host[o], pl->h_ts_x, sizeof(double) * N); o += N;
@@ -310,6 +328,8 @@ int ucf_plan_create(const ucf_params* Pin, ucf_plan** out)
     const size_t o_glw = o; std::memcpy(&host[o], pl->h_gl_w, sizeof(double) * ngl); o += ngl;
     const size_t o_j0z = o; std::memcpy(&host[o], pl->h_j0z, sizeof(double) * D.nj0z); o += D.nj0z;
     const size_t o_fde = o; if (!fd_e.empty()) std::memcpy(&host[o], fd_e.data(), sizeof(double) * fd_e.size());
+    o += fd_e.size();
+    const size_t o_sched = o; if (!sched.empty()) std::memcpy(&host[o], sched.data(), sizeof(double) * sched.size());
     pl->tables_bytes = n_tab * sizeof(double);
     if (hipMalloc((void**)&pl->d_tables, pl->tables_bytes) != hipSuccess) {
         ucf_plan_destroy(pl);
@@ -341,6 +361,7 @@ int ucf_plan_create(const ucf_params* Pin, ucf_plan** out)
     dp.gl_w = pl->d_tables + o_glw;
     dp.j0z = pl->d_tables + o_j0z;
     dp.fd_e = pl->d_tables + o_fde;
+    dp.sched = pl->d_tables + o_sched;
     pl->mode = 0;
     *out = pl;
     return UCF_OK;
@@ -351,6 +372,9 @@ void ucf_plan_destroy(ucf_plan* pl)
     if (!pl) return;
     if (pl->d_tables) (void)hipFree(pl->d_tables);
     if (pl->d_work) (void)hipFree(pl->d_work);
+    if (pl->d_totlap) (void)hipFree(pl->d_totlap);
+    if (pl->ev0) (void)hipEventDestroy((hipEvent_t)pl->ev0);
+    if (pl->ev1) (void)hipEventDestroy((hipEvent_t)pl->ev1);
     std::free(pl->h_j0z); std::free(pl->h_ts_x); std::free(pl->h_ts_w); std::free(pl->h_gl_x); std::free(pl->h_gl_w);
     delete pl;
 }
@@ -389,10 +413,32 @@ int ucf_plan_gauss_lobatto(const ucf_plan* pl, int n, double* x, double* w)
     return UCF_OK;
 }
 
+int ucf_plan_set_timing(ucf_plan* pl, int enable)
+{
+    if (!pl) return fail(UCF_ERR_BAD_ARGUMENT, "NULL plan");
+    pl->timing = enable ? 1 : 0;
+    pl->ev_valid = 0;
+    return UCF_OK;
+}
+
+int ucf_plan_kernel_ms(ucf_plan* pl, double* ms, const char** kernel_name)
+{
+    if (!pl || !ms) return fail(UCF_ERR_BAD_ARGUMENT, "NULL argument");
+    if (!pl->ev_valid) return fail(UCF_ERR_BAD_ARGUMENT, "no timed launch: enable timing and run a single-chunk grid call first");
+    HIP_TRY(hipEventSynchronize((hipEvent_t)pl->ev1));
+    float f = 0.f;
+    HIP_TRY(hipEventElapsedTime(&f, (hipEvent_t)pl->ev0, (hipEvent_t)pl->ev1));
+    *ms = (double)f;
+    if (kernel_name) *kernel_name = pl->last_kernel;
+    return UCF_OK;
+}
+
 int ucf_plan_set_mode(ucf_plan* pl, int mode)
 {
-    if (!pl || (mode != 0 && mode != 1)) return fail(UCF_ERR_BAD_ARGUMENT, "mode must be 0 (faithful) or 1 (fast)");
-    pl->mode = mode;
+    // bit 0: 0 faithful / 1 fast;  bit 1 (diagnostic): force the lane = Laplace-sample layout for grids
+    if (!pl || mode < 0 || mode > 3) return fail(UCF_ERR_BAD_ARGUMENT, "mode must be 0 (faithful) or 1 (fast) [+2: lane=sample layout]");
+    pl->mode = mode & 1;
+    pl->force_layout0 = (mode >> 1) & 1;
     return UCF_OK;
 }
 
@@ -513,6 +559,40 @@ int ucf_drawdown_grid_device(ucf_plan* pl, int nt, const double* d_tD, const int
     if (rc) return rc;
     rc = ucf_faithful::launch_abscissae(dp, nr * nsv, 0, nsv, svmin, d_rD, d_sv, pl->d_work, stream);
     if (rc) return fail(rc, "abscissa kernel launch failed");
+    // lane layout: lane = time (all 64 lanes live, needs one split index for all times) when that fills the
+    // wave better than lane = Laplace sample (2M+1 of 64 lanes)
+    const int ntiles = (nt + UCF_WAVE - 1) / UCF_WAVE;
+    const double fill_time = (double)nt / (64.0 * ntiles), fill_lap = (double)pl->D.np / 64.0;
+    if (nsv == 1 && fill_time > fill_lap && !pl->force_layout0) {
+        const size_t per_radius = (size_t)nt * nz * pl->D.np * 2 * sizeof(double);
+        int nrc = (int)(((size_t)1 << 30) / per_radius);           // <= 1 GiB of workspace per chunk of radii
+        if (nrc < 1) nrc = 1;
+        if (nrc > nr) nrc = nr;
+        if (pl->totlap_bytes < per_radius * nrc) {
+            if (pl->d_totlap) { (void)hipDeviceSynchronize(); (void)hipFree(pl->d_totlap); pl->d_totlap = nullptr; pl->totlap_bytes = 0; }
+            if (hipMalloc((void**)&pl->d_totlap, per_radius * nrc) != hipSuccess)
+                return fail(UCF_ERR_NOMEM, "hipMalloc of %zu transform-workspace bytes failed", per_radius * nrc);
+            pl->totlap_bytes = per_radius * nrc;
+        }
+        // timing brackets the transform kernel of a single-chunk call (the dominant kernel of the path)
+        void* tev0 = nullptr; void* tev1 = nullptr;
+        pl->ev_valid = 0;
+        if (pl->timing && nrc == nr) {
+            if (!pl->ev0) { hipEvent_t a, b; if (hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) { pl->ev0 = a; pl->ev1 = b; } }
+            tev0 = pl->ev0; tev1 = pl->ev1;
+            pl->ev_valid = (tev0 && tev1);
+            pl->last_kernel = (pl->mode == 1) ? "ucf_fast::point_kernel<FAMILY, 1>" : "ucf_faithful::point_kernel<FAMILY, 1>";
+        }
+        for (int ir0 = 0; ir0 < nr; ir0 += nrc) {
+            const int n = (nr - ir0 < nrc) ? nr - ir0 : nrc;
+            rc = (pl->mode == 1)
+                     ? ucf_fast::launch_grid_transposed(dp, nt, nr, ir0, n, svmin, d_tD, d_rD, pl->d_work, pl->d_totlap, d_h, d_dh, d_stats, stream, tev0, tev1)
+                     : ucf_faithful::launch_grid_transposed(dp, nt, nr, ir0, n, svmin, d_tD, d_rD, pl->d_work, pl->d_totlap, d_h, d_dh, d_stats, stream, tev0, tev1);
+            if (rc == UCF_ERR_UNSUPPORTED) return fail(rc, "this model / size combination has no kernel (model %d, LDS limit)", dp.model);
+            if (rc) return fail(rc, "kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+        }
+        return UCF_OK;
+    }
     return launch_points_any(pl, dp, nt * nr, 0, nr, nsv, svmin, d_tD, d_rD, d_sv, d_h, d_dh, d_stats, stream);
 }
 

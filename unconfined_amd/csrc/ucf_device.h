@@ -60,6 +60,15 @@ UCF_DEV cplx cinv_plain_(cplx z)
 // ------------------------------------------------------------------ time.f90:34-80
 UCF_DEV cplx lap_time(const ucf_dev_params& P, cplx p)
 {
+    if (P.timeType < 0) {                                                                        // :81-95
+        const int n = -P.timeType;
+        cplx sum = cmake(0.0, 0.0);
+        for (int k = 0; k < n; k++) {
+            const cplx term = rscale(P.sched[n + k], cexp_(rscale(-P.sched[k], p)));
+            sum = (k == 0) ? term : cadd(sum, term);
+        }
+        return cdiv(csub(sum, rscale(P.sched[2 * n + 1], cexp_(rscale(-P.sched[2 * n], p)))), p);
+    }
     const double t1 = P.timePar[0], t2 = P.timePar[1];
     switch (P.timeType) {
     case 1: return cdiv(cexp_(cscale(p, -t1)), p);                                               // :47-49
@@ -618,11 +627,21 @@ abscissa_kernel(const ucf_dev_params P, int nrows, int per_point, int nsv, int s
 // LDS per wave (slots of 64 complex):  [R*nz] level sums | [nacc*nz] interval areas |
 // [max(nacc,R)] x 32 lanes scratch (Richardson / Wynn run on one half-wave at a time) |
 // FAMILY 4: [2*order] Thomas sweep.
-template <int FAMILY>
+//
+// Two lane layouts of the same body:
+//   LAYOUT 0  lane = Laplace sample p_m of ONE point (2M+1 <= 64 live lanes); de Hoog follows in the same
+//             wave.  Used for arbitrary point lists and short time vectors.
+//   LAYOUT 1  lane = one of 64 consecutive TIMES at one radius, the wave owns one Laplace index m for all of
+//             them (all 64 lanes live whatever M is; abscissa row still wave-uniform).  The accelerated
+//             transform totlap(t, r, z, m) goes to an HBM workspace (16 B per sample point) and
+//             dehoog_points_kernel inverts it with lane = m.  Per-lane arithmetic is identical to LAYOUT 0,
+//             so both give the same bits.
+template <int FAMILY, int LAYOUT>
 __global__ void __launch_bounds__(UCF_WAVE, 2)
 point_kernel(const ucf_dev_params P, int npts, int per_point, int nr, int nsv, int svmin,
              const double* __restrict__ tDv, const double* __restrict__ rDv, const int* __restrict__ svv,
-             const double2* __restrict__ tab, double* __restrict__ hout, double* __restrict__ dhout, ucf_stats* st)
+             const double2* __restrict__ tab, double* __restrict__ hout, double* __restrict__ dhout, ucf_stats* st,
+             int nt, int ir0, int nrc, double2* __restrict__ totlap)
 {
     extern __shared__ lds_c lds[];
     const int lane = threadIdx.x;
@@ -637,14 +656,30 @@ point_kernel(const ucf_dev_params P, int npts, int per_point, int nr, int nsv, i
     for (int z = 0; z < nz; z++) need_lay1 |= (P.zLay[z] == 1);
 
     for (int pt = blockIdx.x; pt < npts; pt += gridDim.x) {
-        const int it = per_point ? pt : pt / nr;
-        const int ir = per_point ? pt : pt % nr;
+        int it, ir, mlap;
+        bool live;
+        if (LAYOUT == 0) {
+            it = per_point ? pt : pt / nr;
+            ir = per_point ? pt : pt % nr;
+            mlap = lane;
+            live = lane < P.np;
+        } else {
+            // work item = (radius of this chunk, tile of 64 times, Laplace index); m fastest so that
+            // neighbouring waves share the abscissa row and the times
+            const int ntiles = (nt + UCF_WAVE - 1) / UCF_WAVE;
+            mlap = pt % P.np;
+            const int tile = (pt / P.np) % ntiles;
+            ir = ir0 + pt / (P.np * ntiles);
+            it = tile * UCF_WAVE + lane;
+            live = it < nt;
+            if (!live) it = nt - 1;
+        }
         const double tD = tDv[it], rD = rDv[ir];
-        const int sv = svv[it];
+        const int sv = (LAYOUT == 0) ? svv[it] : svmin;
         const double2* __restrict__ row = tab + (size_t)(per_point ? pt : (ir * nsv + (sv - svmin))) * nabs;
         const double tee = 2.0 * tD;                                                            // driver.f90:106,217
         const double sigma = P.alpha - P.logtol / (2.0 * tee);                                  // invlap.f90:165
-        const cplx p = cmake(sigma, UCF_PI * lane / tee);                                       // invlap.f90:168
+        const cplx p = cmake(sigma, UCF_PI * mlap / tee);                                       // invlap.f90:168
         const cplx lt = lap_time(P, p);
         const double arg = P.j0z[sv - 1] / rD;                                                  // driver.f90:120
 #if UCF_FAST
@@ -721,18 +756,56 @@ point_kernel(const ucf_dev_params P, int npts, int per_point, int nr, int nsv, i
                 }
             }
             if (st) {
-                const bool live = lane < P.np;
                 stat_add(&st->wynn_all_zero, live && !any);
                 stat_add(&st->wynn_truncated, live && wst == 1);
                 stat_add(&st->wynn_sentinel, live && wst == 2);
                 stat_add(&st->wynn_early_exit, live && wst == 3);
             }
-            const cplx totlap = cadd(finint, infint);                                           // :216
-            const double hval = dehoog_wave(totlap, P.M, P.alpha, P.logtol, tD, tee, lane, st);  // :219-223
-            const double dval = dehoog_wave(cmul(totlap, p), P.M, P.alpha, P.logtol, tD, tee, lane, st) * tD;   // :225-230
+            const cplx tl = cadd(finint, infint);                                               // :216
+            if (LAYOUT == 1) {
+                if (live) {
+                    const size_t lp = (size_t)it * nrc + (ir - ir0);
+                    totlap[(lp * nz + z) * P.np + mlap] = make_double2(tl.re, tl.im);
+                }
+            } else {
+                const double hval = dehoog_wave(tl, P.M, P.alpha, P.logtol, tD, tee, lane, st);  // :219-223
+                const double dval = dehoog_wave(cmul(tl, p), P.M, P.alpha, P.logtol, tD, tee, lane, st) * tD;   // :225-230
+                if (lane == 0) {
+                    hout[(size_t)pt * nz + z] = hval;
+                    dhout[(size_t)pt * nz + z] = dval;
+                }
+            }
+        }
+    }
+}
+
+// second half of LAYOUT 1: one wave per (t, r) point of the chunk, lane = Laplace index (driver.f90:217-230)
+__global__ void __launch_bounds__(UCF_WAVE)
+dehoog_points_kernel(const ucf_dev_params P, int nt, int nr, int ir0, int nrc, const double* __restrict__ tDv,
+                     const double2* __restrict__ totlap, double* __restrict__ hout, double* __restrict__ dhout,
+                     ucf_stats* st)
+{
+    const int lane = threadIdx.x;
+    const int nz = P.nz;
+    const long long npc = (long long)nt * nrc;
+    for (long long lp = blockIdx.x; lp < npc; lp += gridDim.x) {
+        const int it = (int)(lp / nrc), irl = (int)(lp % nrc);
+        const double tD = tDv[it];
+        const double tee = 2.0 * tD;
+        const double sigma = P.alpha - P.logtol / (2.0 * tee);
+        const cplx p = cmake(sigma, UCF_PI * lane / tee);
+        for (int z = 0; z < nz; z++) {
+            cplx tl = cmake(0.0, 0.0);
+            if (lane < P.np) {
+                const double2 v = totlap[((size_t)lp * nz + z) * P.np + lane];
+                tl = cmake(v.x, v.y);
+            }
+            const double hval = dehoog_wave(tl, P.M, P.alpha, P.logtol, tD, tee, lane, st);
+            const double dval = dehoog_wave(cmul(tl, p), P.M, P.alpha, P.logtol, tD, tee, lane, st) * tD;
             if (lane == 0) {
-                hout[(size_t)pt * nz + z] = hval;
-                dhout[(size_t)pt * nz + z] = dval;
+                const size_t o = ((size_t)it * nr + ir0 + irl) * nz + z;
+                hout[o] = hval;
+                dhout[o] = dval;
             }
         }
     }
@@ -899,9 +972,9 @@ int launch_points(const ucf_dev_params& dp, int npts, int per_point, int nr, int
 #define UCF_LAUNCH(F)                                                                                          \
     do {                                                                                                       \
         if (lds > 64 * 1024)                                                                                   \
-            (void)hipFuncSetAttribute((const void*)point_kernel<F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL(point_kernel<F>, grid, block, lds, s, dp, npts, per_point, nr, nsv, svmin, d_tD, d_rD, d_sv,   \
-                           (const double2*)d_tab, d_h, d_dh, d_stats);                                         \
+            (void)hipFuncSetAttribute((const void*)point_kernel<F, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((point_kernel<F, 0>), grid, block, lds, s, dp, npts, per_point, nr, nsv, svmin, d_tD, d_rD, d_sv, \
+                           (const double2*)d_tab, d_h, d_dh, d_stats, 0, 0, 0, (double2*)nullptr);            \
     } while (0)
     switch (fam) {
     case 0: UCF_LAUNCH(0); break;
@@ -912,6 +985,45 @@ int launch_points(const ucf_dev_params& dp, int npts, int per_point, int nr, int
     case 5: UCF_LAUNCH(5); break;
     }
 #undef UCF_LAUNCH
+    return hipGetLastError() == hipSuccess ? UCF_OK : UCF_ERR_HIP;
+}
+
+// LAYOUT 1 (lane = time): transform kernel over (radius chunk x time tiles x Laplace index), then de Hoog
+int launch_grid_transposed(const ucf_dev_params& dp, int nt, int nr, int ir0, int nrc, int svmin, const double* d_tD,
+                           const double* d_rD, const double* d_tab, double* d_totlap, double* d_h, double* d_dh,
+                           ucf_stats* d_stats, void* stream, void* ev0, void* ev1)
+{
+    const int fam = family_of(dp);
+    if (fam < 0) return UCF_ERR_UNSUPPORTED;
+    const size_t lds = point_lds_bytes(dp);
+    if (lds > 160 * 1024) return UCF_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    if (ev0) (void)hipEventRecord((hipEvent_t)ev0, s);
+    const int ntiles = (nt + UCF_WAVE - 1) / UCF_WAVE;
+    const long long nwork = (long long)nrc * ntiles * dp.np;
+    if (nwork > 0x7fffffffLL) return UCF_ERR_BAD_ARGUMENT;
+    dim3 grid((unsigned)nwork), block(UCF_WAVE);
+#define UCF_LAUNCH(F)                                                                                          \
+    do {                                                                                                       \
+        if (lds > 64 * 1024)                                                                                   \
+            (void)hipFuncSetAttribute((const void*)point_kernel<F, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((point_kernel<F, 1>), grid, block, lds, s, dp, (int)nwork, 0, nr, 1, svmin, d_tD, d_rD,           \
+                           (const int*)nullptr, (const double2*)d_tab, d_h, d_dh, d_stats, nt, ir0, nrc, (double2*)d_totlap); \
+    } while (0)
+    switch (fam) {
+    case 0: UCF_LAUNCH(0); break;
+    case 1: UCF_LAUNCH(1); break;
+    case 2: UCF_LAUNCH(2); break;
+    case 3: UCF_LAUNCH(3); break;
+    case 4: UCF_LAUNCH(4); break;
+    case 5: UCF_LAUNCH(5); break;
+    }
+#undef UCF_LAUNCH
+    if (ev1) (void)hipEventRecord((hipEvent_t)ev1, s);
+    if (hipGetLastError() != hipSuccess) return UCF_ERR_HIP;
+    const long long npc = (long long)nt * nrc;
+    hipLaunchKernelGGL(dehoog_points_kernel, dim3((unsigned)(npc > 0x7fffffffLL ? 0x7fffffff : npc)), block, 0, s, dp, nt, nr, ir0,
+                       nrc, d_tD, (const double2*)d_totlap, d_h, d_dh, d_stats);
     return hipGetLastError() == hipSuccess ? UCF_OK : UCF_ERR_HIP;
 }
 

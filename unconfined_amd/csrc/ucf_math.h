@@ -41,7 +41,16 @@ UCF_DEV cplx cmake(double re, double im) { cplx z; z.re = re; z.im = im; return 
 UCF_DEV cplx cadd(cplx a, cplx b) { return cmake(a.re + b.re, a.im + b.im); }
 UCF_DEV cplx csub(cplx a, cplx b) { return cmake(a.re - b.re, a.im - b.im); }
 UCF_DEV cplx cneg(cplx a) { return cmake(-a.re, -a.im); }
+#if UCF_FAST
+// explicit FMA form: the same bits wherever it is inlined (a free-form expression is contracted differently
+// in different contexts under -ffp-contract=fast)
+UCF_DEV cplx cmul(cplx a, cplx b)
+{
+    return cmake(__builtin_fma(a.re, b.re, -(a.im * b.im)), __builtin_fma(a.re, b.im, a.im * b.re));
+}
+#else
 UCF_DEV cplx cmul(cplx a, cplx b) { return cmake(a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re); }
+#endif
 UCF_DEV cplx cscale(cplx a, double s) { return cmake(a.re * s, a.im * s); }    // complex*real
 UCF_DEV cplx rscale(double s, cplx a) { return cmake(s * a.re, s * a.im); }    // real*complex
 UCF_DEV cplx caddr(cplx a, double s) { return cmake(a.re + s, a.im); }         // complex+real

@@ -35,6 +35,7 @@ struct ucf_dev_params {
     const double* gl_w;    // [ngl]
     const double* j0z;     // [nj0z]
     const double* fd_e;    // [order]  exp(-beta1*(j-1)*h)
+    const double* sched;   // timeType = -n: [n] start times | [n] rate increments | final time | sum of increments
 };
 
 struct ucf_plan {
@@ -42,6 +43,12 @@ struct ucf_plan {
     ucf_derived D;
     ucf_dev_params dev;        // zD/zLay/nz filled per call
     int mode;                  // 0 faithful, 1 fast
+    int force_layout0;         // diagnostic: never use the lane = time layout
+    int timing;                // bracket the dominant kernel with events
+    void* ev0;                 // hipEvent_t
+    void* ev1;
+    int ev_valid;
+    const char* last_kernel;
     int device;
     double* d_tables;          // one allocation holding all tables
     size_t tables_bytes;
@@ -55,6 +62,9 @@ struct ucf_plan {
     // abscissa-table workspace (grown on demand, never shrunk)
     double* d_work;
     size_t work_bytes;
+    // LAYOUT 1 workspace: accelerated transform totlap(t, r, z, m), 16 B each
+    double* d_totlap;
+    size_t totlap_bytes;
 };
 
 // launchers implemented in ucf_kernels.hip (one set per build flavour)
@@ -65,6 +75,9 @@ int launch_abscissae(const ucf_dev_params& dp, int nrows, int per_point, int nsv
 int launch_points(const ucf_dev_params& dp, int npts, int per_point, int nr, int nsv, int svmin, const double* d_tD,
                   const double* d_rD, const int* d_sv, const double* d_tab, double* d_h, double* d_dh,
                   ucf_stats* d_stats, void* stream);
+int launch_grid_transposed(const ucf_dev_params& dp, int nt, int nr, int ir0, int nrc, int svmin, const double* d_tD,
+                           const double* d_rD, const double* d_tab, double* d_totlap, double* d_h, double* d_dh,
+                           ucf_stats* d_stats, void* stream, void* ev0, void* ev1);
 int launch_samples(const ucf_dev_params& dp, int n_a, const double* d_a, double rD, const double* d_p, double* d_fp,
                    void* stream);
 int launch_bessel(int n, const double* d_z, double* d_k, int* d_ierr, void* stream);
@@ -74,6 +87,9 @@ int launch_wynn(int n, int nterms, const double* d_series, double* d_acc, int* d
 int launch_extrap(int n, int R, const double* d_x, const double* d_y, double* d_out, void* stream);
 }
 namespace ucf_fast {
+int launch_grid_transposed(const ucf_dev_params& dp, int nt, int nr, int ir0, int nrc, int svmin, const double* d_tD,
+                           const double* d_rD, const double* d_tab, double* d_totlap, double* d_h, double* d_dh,
+                           ucf_stats* d_stats, void* stream, void* ev0, void* ev1);
 int launch_points(const ucf_dev_params& dp, int npts, int per_point, int nr, int nsv, int svmin, const double* d_tD,
                   const double* d_rD, const int* d_sv, const double* d_tab, double* d_h, double* d_dh,
                   ucf_stats* d_stats, void* stream);

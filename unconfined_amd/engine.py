@@ -38,14 +38,14 @@ class Plan:
     """Immutable per-parameter-set state: dimensionless parameters, J0 zeros,
     tanh-sinh / Gauss-Lobatto tables (resident on the GPU)."""
 
-    def __init__(self, params: UcfParams, mode: str = "faithful"):
+    def __init__(self, params: UcfParams, mode: str = "faithful", layout: str = "auto"):
         self._lib = _libmod.load()
         self._h = C.c_void_p()
         self.params = params
         _libmod.check(self._lib.ucf_plan_create(C.byref(params), C.byref(self._h)))
         self.derived = UcfDerived()
         _libmod.check(self._lib.ucf_plan_derived(self._h, C.byref(self.derived)))
-        self.set_mode(mode)
+        self.set_mode(mode, layout)
 
     @classmethod
     def from_deck(cls, dk: Deck, mode: str = "faithful") -> "Plan":
@@ -62,10 +62,23 @@ class Plan:
         except Exception:
             pass
 
-    def set_mode(self, mode: str):
-        m = {"faithful": 0, "fast": 1}[mode]
+    def set_mode(self, mode: str, layout: str = "auto"):
+        """mode: 'faithful' | 'fast'; layout (grids only): 'auto' picks lane = time when that fills the
+        wave better, 'sample' forces lane = Laplace sample (diagnostic / A-B timing)"""
+        m = {"faithful": 0, "fast": 1}[mode] | ({"auto": 0, "sample": 2}[layout])
         _libmod.check(self._lib.ucf_plan_set_mode(self._h, m))
         self.mode = mode
+        self.layout = layout
+
+    def set_timing(self, enable: bool = True):
+        _libmod.check(self._lib.ucf_plan_set_timing(self._h, 1 if enable else 0))
+
+    def kernel_ms(self):
+        """(duration in ms, kernel name) of the dominant kernel of the last timed grid call"""
+        ms = C.c_double(0.0)
+        name = C.c_char_p()
+        _libmod.check(self._lib.ucf_plan_kernel_ms(self._h, C.byref(ms), C.byref(name)))
+        return ms.value, (name.value or b"").decode()
 
     # ---- tables (read back for parity tests / headers)
     def j0z(self) -> np.ndarray:

@@ -10,6 +10,7 @@ module ucf_binding
   private
 
   integer(c_int), parameter, public :: UCF_MAX_MOENCH = 16
+  integer(c_int), parameter, public :: UCF_MAX_SCHEDULE = 100
   integer(c_int), parameter, public :: UCF_OK = 0
 
   type, bind(C), public :: ucf_params
@@ -21,6 +22,7 @@ module ucf_binding
      real(c_double) :: ac, ak, psia, psik, usL
      integer(c_int) :: M, k, R, nacc, ord, j0s(2), pad1
      real(c_double) :: alpha, tol, rwobs, sF
+     real(c_double) :: timeParExt(2*UCF_MAX_SCHEDULE+1)
   end type ucf_params
 
   type, bind(C), public :: ucf_derived

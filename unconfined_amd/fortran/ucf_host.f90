@@ -16,8 +16,9 @@ program ucf_host
   type(ucf_derived) :: D
   type(ucf_stats) :: st
   type(c_ptr) :: plan
-  character(len=512) :: deckname, modearg, line, tfile, sfile, outname
-  character(len=64) :: tok(24)
+  character(len=512) :: deckname, modearg, tfile, sfile, outname
+  character(len=8192) :: line
+  character(len=64) :: tok(256)
   integer :: ntok, quiet, zOrd, ios, mode, i, k, m, u
   logical :: dimless, timeseries, piezometer, compute
   real(c_double) :: tval, rval, zTop, zBot, sc
@@ -43,7 +44,19 @@ program ucf_host
   call rec(u, 2); P%l = num(tok(1)); P%d = num(tok(2))
   call rec(u, 2); P%rw = num(tok(1)); P%rc = num(tok(2))
   call rec(u, 1); P%gammaSkin = num(tok(1))
-  call rec(u, 3); read(tok(1),*) P%timeType; P%timePar(1) = num(tok(2)); P%timePar(2) = num(tok(3))
+  call rec(u, 1); read(tok(1),*) P%timeType
+  P%timePar = 0.0_c_double; P%timeParExt = 0.0_c_double
+  if (P%timeType > -1) then
+     if (ntok < 3) call die('time behaviour needs two parameters')
+     P%timePar(1) = num(tok(2)); P%timePar(2) = num(tok(3))
+  else                                   ! -n: 2n+1 schedule parameters (driver_io.f90:119-127)
+     k = 2*mod(-P%timeType, 100) + 1
+     if (k > 2*UCF_MAX_SCHEDULE+1 .or. ntok < 1 + k) call die('pumping schedule: wrong number of parameters')
+     do i = 1, k
+        P%timeParExt(i) = num(tok(1+i))
+     end do
+     P%timePar(1) = P%timeParExt(1); P%timePar(2) = P%timeParExt(2)
+  end if
   call rec(u, 1); P%b = num(tok(1))
   call rec(u, 2); P%Kr = num(tok(1)); P%kappa = num(tok(2))
   call rec(u, 2); P%Ss = num(tok(1)); P%Sy = num(tok(2))

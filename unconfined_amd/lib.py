@@ -23,7 +23,7 @@ _ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
 EXPORTS = [
     "ucf_version", "ucf_last_error", "ucf_status_string",
     "ucf_plan_create", "ucf_plan_destroy", "ucf_plan_derived", "ucf_plan_j0z", "ucf_plan_tanh_sinh",
-    "ucf_plan_gauss_lobatto", "ucf_plan_set_mode",
+    "ucf_plan_gauss_lobatto", "ucf_plan_set_mode", "ucf_plan_set_timing", "ucf_plan_kernel_ms",
     "ucf_logspace", "ucf_linspace", "ucf_zlay", "ucf_split_vector",
     "ucf_drawdown_batch", "ucf_drawdown_batch_device", "ucf_drawdown_grid", "ucf_drawdown_grid_device",
     "ucf_screen_average",
@@ -74,6 +74,8 @@ def load() -> C.CDLL:
     lib.ucf_plan_tanh_sinh.argtypes = [vp, C.c_int, C.c_int, _dp, vp]
     lib.ucf_plan_gauss_lobatto.argtypes = [vp, C.c_int, _dp, _dp]
     lib.ucf_plan_set_mode.argtypes = [vp, C.c_int]
+    lib.ucf_plan_set_timing.argtypes = [vp, C.c_int]
+    lib.ucf_plan_kernel_ms.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_char_p)]
     lib.ucf_logspace.argtypes = [C.c_int, C.c_int, C.c_int, _dp]
     lib.ucf_linspace.argtypes = [C.c_double, C.c_double, C.c_int, _dp]
     lib.ucf_zlay.argtypes = [vp, C.c_int, _dp, _ip]
