@@ -35,7 +35,7 @@ extern "C" {
 #define UCF_MAX_MOENCH 16      /* max number of Moench alphas (driver_io.f90:142-151) */
 #define UCF_MAX_NZ 32          /* max depths per point handled by one launch */
 #define UCF_MAX_SCHEDULE 100    /* steps of a piecewise-constant pumping schedule (time.f90:81-95) */
-#define UCF_MAX_LAP_M 31       /* 2M+1 <= 64: one Laplace sample per lane of a wave */
+#define UCF_MAX_LAP_M 63       /* 2M+1 <= 128: the wave-cooperative de Hoog holds at most two samples per lane */
 
 typedef enum ucf_status {
     UCF_OK = 0,

@@ -319,7 +319,7 @@ def test_full_size_properties(engine, oracle):
     assert dev.max() < 1e-4, float(dev.max())
 
 
-def test_edge_cases(engine, oracle):
+def test_edge_cases(engine, oracle, oracle_quad):
     """empty batch, a single point, ragged (non multiple of 64) batch, nz > 1, maximum M, the
     overflow regime rD = 0.02 (NaN scrub / Wynn truncation rules) and bad arguments"""
     from unconfined_amd.lib import UcfError
@@ -350,12 +350,22 @@ def test_edge_cases(engine, oracle):
         plan.drawdown(np.array([1.0]), np.array([1.0]), np.array([99], np.int32), zD, zl)     # sv beyond the J0 table
     with pytest.raises(UcfError):
         plan.drawdown(np.array([1.0]), np.array([1.0]), np.array([1], np.int32), zD, np.array([1, 2, 7], np.int32))
-    # maximum number of Laplace samples per wave
-    Pm = type(P).from_buffer_copy(P); Pm.M = 31
-    pm = engine.Plan(Pm)
-    h, dh = pm.drawdown(np.array([1.0]), np.array([0.5]), np.array([1], np.int32), zD[:1], zl[:1])
-    ho, dho = oracle.batch(Pm, np.array([1.0]), np.array([0.5]), np.array([1], np.int32), zD[:1], zl[:1])
-    assert rel_err(h, ho, 1e-6).max() < 1e-8
+    # Laplace sample counts around the wave width: 2M+1 = 63 (one per lane), 65 and 127 (two per lane)
+    tDm = np.array([0.05, 1.0, 40.0]); rDm = np.array([0.5, 0.5, 0.5]); svm = np.ones(3, np.int32)
+    for M in (31, 32, 63):
+        Pm = type(P).from_buffer_copy(P); Pm.M = M
+        pm = engine.Plan(Pm)
+        h, dh = pm.drawdown(tDm, rDm, svm, zD[:2], zl[:2])
+        ho, dho = oracle.batch(Pm, tDm, rDm, svm, zD[:2], zl[:2])
+        if M < 63:
+            assert rel_err(h, ho, 1e-6).max() < 1e-7, M
+        else:
+            # 127 Laplace samples: the QD table amplifies rounding so much that only the comparison with
+            # exact arithmetic is meaningful -- the device must be as close to it as the binary64 oracle is
+            ht, dht = oracle_quad.batch(Pm, tDm, rDm, svm, zD[:2], zl[:2], threads=8)
+            assert rel_err(h, ht, 1e-6).max() <= max(1e-9, 10.0 * rel_err(ho, ht, 1e-6).max()), (M, rel_err(h, ht, 1e-6).max(), rel_err(ho, ht, 1e-6).max())
+        hg, dg = pm.drawdown_grid(tDm, svm, rDm[:1], zD[:2], zl[:2])
+        assert np.array_equal(hg[:, 0, :], h), M            # grid (lane = time) and per-point entries: same bits
 
 
 def test_smoke_entry():

@@ -78,7 +78,7 @@ int validate(const ucf_params& P)
         for (int i = 0; i < P.MoenchM; i++)
             if (P.MoenchAlpha[i] < 0.0) return fail(UCF_ERR_MOENCH, "Moench alphas cannot be negative");
     if (P.M < 2) return fail(UCF_ERR_DEHOOG, "de Hoog M must be >= 2 (M=%d)", P.M);
-    if (P.M > UCF_MAX_LAP_M) return fail(UCF_ERR_UNSUPPORTED, "de Hoog M=%d: this build maps one Laplace sample per lane (M <= %d)", P.M, UCF_MAX_LAP_M);
+    if (P.M > UCF_MAX_LAP_M) return fail(UCF_ERR_UNSUPPORTED, "de Hoog M=%d: the wave-cooperative inversion holds at most two Laplace samples per lane (M <= %d)", P.M, UCF_MAX_LAP_M);
     if (P.k - P.R < 2) return fail(UCF_ERR_TANH_SINH, "tanh-sinh k (%d) too low for %d Richardson levels", P.k, P.R);
     if (P.R < 1) return fail(UCF_ERR_TANH_SINH, "Richardson extrapolation level must be >= 1");
     if (P.R > UCF_MAX_R || P.k > 20) return fail(UCF_ERR_UNSUPPORTED, "tanh-sinh k=%d R=%d beyond build limits", P.k, P.R);
@@ -529,9 +529,23 @@ int launch_points_any(ucf_plan* pl, const ucf_dev_params& dp, int npts, int per_
                       const double* d_tD, const double* d_rD, const int* d_sv, double* d_h, double* d_dh,
                       ucf_stats* d_stats, void* stream)
 {
-    int rc = (pl->mode == 1)
+    int rc;
+    if (pl->D.np > UCF_WAVE) {
+        // more Laplace samples than lanes: (point, 64-sample chunk) work items + separate inversion kernel
+        const size_t need = (size_t)npts * dp.nz * pl->D.np * 2 * sizeof(double);
+        if (pl->totlap_bytes < need) {
+            if (pl->d_totlap) { (void)hipDeviceSynchronize(); (void)hipFree(pl->d_totlap); pl->d_totlap = nullptr; pl->totlap_bytes = 0; }
+            if (hipMalloc((void**)&pl->d_totlap, need) != hipSuccess) return fail(UCF_ERR_NOMEM, "hipMalloc of %zu transform-workspace bytes failed", need);
+            pl->totlap_bytes = need;
+        }
+        rc = (pl->mode == 1)
+                 ? ucf_fast::launch_points_chunked(dp, npts, per_point, nr, nsv, svmin, d_tD, d_rD, d_sv, pl->d_work, pl->d_totlap, d_h, d_dh, d_stats, stream)
+                 : ucf_faithful::launch_points_chunked(dp, npts, per_point, nr, nsv, svmin, d_tD, d_rD, d_sv, pl->d_work, pl->d_totlap, d_h, d_dh, d_stats, stream);
+    } else {
+        rc = (pl->mode == 1)
                  ? ucf_fast::launch_points(dp, npts, per_point, nr, nsv, svmin, d_tD, d_rD, d_sv, pl->d_work, d_h, d_dh, d_stats, stream)
                  : ucf_faithful::launch_points(dp, npts, per_point, nr, nsv, svmin, d_tD, d_rD, d_sv, pl->d_work, d_h, d_dh, d_stats, stream);
+    }
     if (rc == UCF_ERR_UNSUPPORTED) return fail(rc, "this model / size combination has no kernel (model %d, LDS limit)", dp.model);
     if (rc) return fail(rc, "kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
     return UCF_OK;
@@ -562,7 +576,8 @@ int ucf_drawdown_grid_device(ucf_plan* pl, int nt, const double* d_tD, const int
     // lane layout: lane = time (all 64 lanes live, needs one split index for all times) when that fills the
     // wave better than lane = Laplace sample (2M+1 of 64 lanes)
     const int ntiles = (nt + UCF_WAVE - 1) / UCF_WAVE;
-    const double fill_time = (double)nt / (64.0 * ntiles), fill_lap = (double)pl->D.np / 64.0;
+    const double fill_time = (double)nt / (64.0 * ntiles);
+    const double fill_lap = (double)pl->D.np / (64.0 * ((pl->D.np + 63) / 64));
     if (nsv == 1 && fill_time > fill_lap && !pl->force_layout0) {
         const size_t per_radius = (size_t)nt * nz * pl->D.np * 2 * sizeof(double);
         int nrc = (int)(((size_t)1 << 30) / per_radius);           // <= 1 GiB of workspace per chunk of radii

@@ -498,6 +498,98 @@ UCF_DEV double dehoog_wave(cplx f, int M, double alpha, double logtol, double t,
     return exp(gamma * t) / tee * cdiv(A2M, B2M).re;                                            // :129
 }
 
+// Same algorithm for 64 < 2M+1 <= 128: element i = lane + 64 g lives in register set g of its lane
+// (M up to 63).  Used by dehoog_points_kernel only; elementwise identical to dehoog_wave.
+UCF_DEV void shift_down_128(const cplx (&in)[2], cplx (&out)[2], int lane)
+{
+    const cplx a = shfl_down1(in[0]), b = shfl_down1(in[1]);
+    const cplx b0 = bcast0(in[1]);
+    out[0] = (lane == 63) ? b0 : a;
+    out[1] = b;
+}
+
+UCF_DEV double dehoog_wave2(const cplx (&f)[2], int M, double alpha, double logtol, double t, double tee, int lane,
+                            ucf_stats* st)
+{
+    const int n2 = 2 * M;
+    double mag = 0.0;
+    cplx ff[2], q[2], e[2];
+    bool anynan = false;
+#pragma unroll
+    for (int g = 0; g < 2; g++) {
+        const int i = lane + 64 * g;
+        const bool act = i <= n2;
+        double m1 = act ? cabs_(f[g]) : 0.0;
+        if (d_isnan(m1)) m1 = 0.0;
+        mag = fmax(mag, m1);
+        const bool nanp = act && (d_isnan(f[g].re) || d_isnan(f[g].im));
+        anynan |= nanp;
+        ff[g] = (nanp || !act) ? cmake(act ? 0.0 : 1.0, 0.0) : f[g];
+    }
+    const double mx = wave_max(mag);
+    if (!(mx > UCF_DBL_MIN)) {
+        if (st) stat_add(&st->zero_vectors, lane == 0);
+        return 0.0;
+    }
+    if (st) stat_add(&st->nan_scrubbed, anynan);
+    const double gamma = alpha - logtol / (2.0 * tee);
+    const cplx ff0 = bcast0(ff[0]);
+    const cplx d0 = cdivr(ff0, 2.0);
+    cplx fn[2];
+    shift_down_128(ff, fn, lane);
+#pragma unroll
+    for (int g = 0; g < 2; g++) {
+        const int i = lane + 64 * g;
+        q[g] = (i == 0) ? cdiv(fn[g], d0) : cdiv(fn[g], ff[g]);
+        if (i > n2 - 1) q[g] = cmake(1.0, 0.0);
+        e[g] = cmake(0.0, 0.0);
+    }
+    cplx Am2 = cmake(0.0, 0.0), Am1 = d0, Bm2 = cmake(1.0, 0.0), Bm1 = cmake(1.0, 0.0);
+    const cplx z = cexp_(cdivr(cscale(cscale(cmake(0.0, 1.0), UCF_PI), t), tee));
+    cplx dlast_q = cmake(0.0, 0.0), dlast_e = cmake(0.0, 0.0);
+    for (int r = 1; r <= M; r++) {
+        cplx qn[2], en[2], enew[2];
+        shift_down_128(q, qn, lane);
+        shift_down_128(e, en, lane);
+#pragma unroll
+        for (int g = 0; g < 2; g++) {
+            const int i = lane + 64 * g;
+            enew[g] = cadd(csub(qn[g], q[g]), en[g]);
+            if (i > 2 * (M - r)) enew[g] = cmake(1.0, 0.0);
+        }
+        const cplx dq = cneg(bcast0(q[0]));
+        const cplx de = cneg(bcast0(enew[0]));
+        {
+            cplx An = cadd(Am1, cmul(cmul(dq, Am2), z));
+            cplx Bn = cadd(Bm1, cmul(cmul(dq, Bm2), z));
+            Am2 = Am1; Am1 = An; Bm2 = Bm1; Bm1 = Bn;
+        }
+        if (r < M) {
+            cplx An = cadd(Am1, cmul(cmul(de, Am2), z));
+            cplx Bn = cadd(Bm1, cmul(cmul(de, Bm2), z));
+            Am2 = Am1; Am1 = An; Bm2 = Bm1; Bm1 = Bn;
+            cplx enn[2];
+            shift_down_128(enew, enn, lane);
+#pragma unroll
+            for (int g = 0; g < 2; g++) {
+                const int i = lane + 64 * g;
+                q[g] = cdiv(cmul(qn[g], enn[g]), enew[g]);
+                if (i > 2 * (M - r - 1) + 1) q[g] = cmake(1.0, 0.0);
+                e[g] = enew[g];
+            }
+        } else {
+            dlast_q = dq;
+            dlast_e = de;
+        }
+    }
+    const cplx brem = cdivr(radd(1.0, cmul(csub(dlast_q, dlast_e), z)), 2.0);
+    const cplx inner = csqrt_(radd(1.0, cdiv(cmul(dlast_e, z), cmul(brem, brem))));
+    const cplx rem = cneg(cmul(brem, rsub(1.0, inner)));
+    const cplx A2M = cadd(Am1, cmul(rem, Am2));
+    const cplx B2M = cadd(Bm1, cmul(rem, Bm2));
+    return exp(gamma * t) / tee * cdiv(A2M, B2M).re;
+}
+
 // ------------------------------------------------------------- integration.f90:125-189
 // Per-lane Wynn-epsilon on LDS columns.  colA[(i*strideA)][lane] holds series(i+1) on
 // entry (overwritten by the even epsilon columns); colB is half-wave scratch (odd columns).
@@ -663,6 +755,14 @@ point_kernel(const ucf_dev_params P, int npts, int per_point, int nr, int nsv, i
             ir = per_point ? pt : pt % nr;
             mlap = lane;
             live = lane < P.np;
+        } else if (LAYOUT == 2) {
+            // 2M+1 > 64: work item = (point, chunk of 64 Laplace samples); inversion in dehoog_points_kernel
+            const int nchunk = (P.np + UCF_WAVE - 1) / UCF_WAVE;
+            const int q = pt / nchunk;
+            it = per_point ? q : q / nr;
+            ir = per_point ? q : q % nr;
+            mlap = (pt % nchunk) * UCF_WAVE + lane;
+            live = mlap < P.np;
         } else {
             // work item = (radius of this chunk, tile of 64 times, Laplace index); m fastest so that
             // neighbouring waves share the abscissa row and the times
@@ -675,8 +775,9 @@ point_kernel(const ucf_dev_params P, int npts, int per_point, int nr, int nsv, i
             if (!live) it = nt - 1;
         }
         const double tD = tDv[it], rD = rDv[ir];
-        const int sv = (LAYOUT == 0) ? svv[it] : svmin;
-        const double2* __restrict__ row = tab + (size_t)(per_point ? pt : (ir * nsv + (sv - svmin))) * nabs;
+        const int sv = (LAYOUT == 1) ? svmin : svv[it];
+        const int pidx = (LAYOUT == 2) ? pt / ((P.np + UCF_WAVE - 1) / UCF_WAVE) : pt;     // point index of this work item
+        const double2* __restrict__ row = tab + (size_t)(per_point ? pidx : (ir * nsv + (sv - svmin))) * nabs;
         const double tee = 2.0 * tD;                                                            // driver.f90:106,217
         const double sigma = P.alpha - P.logtol / (2.0 * tee);                                  // invlap.f90:165
         const cplx p = cmake(sigma, UCF_PI * mlap / tee);                                       // invlap.f90:168
@@ -767,6 +868,8 @@ point_kernel(const ucf_dev_params P, int npts, int per_point, int nr, int nsv, i
                     const size_t lp = (size_t)it * nrc + (ir - ir0);
                     totlap[(lp * nz + z) * P.np + mlap] = make_double2(tl.re, tl.im);
                 }
+            } else if (LAYOUT == 2) {
+                if (live) totlap[((size_t)pidx * nz + z) * P.np + mlap] = make_double2(tl.re, tl.im);
             } else {
                 const double hval = dehoog_wave(tl, P.M, P.alpha, P.logtol, tD, tee, lane, st);  // :219-223
                 const double dval = dehoog_wave(cmul(tl, p), P.M, P.alpha, P.logtol, tD, tee, lane, st) * tD;   // :225-230
@@ -779,33 +882,53 @@ point_kernel(const ucf_dev_params P, int npts, int per_point, int nr, int nsv, i
     }
 }
 
-// second half of LAYOUT 1: one wave per (t, r) point of the chunk, lane = Laplace index (driver.f90:217-230)
+// second half of LAYOUTs 1 and 2: one wave per point of the chunk, lane = Laplace index (driver.f90:217-230).
+// flat = 0: chunk-local point lp = it*nrc + irl, output at (it*nr + ir0 + irl);  flat = 1: lp is the point itself
+// (tD per point when per_point, else tD[lp / nr]).
 __global__ void __launch_bounds__(UCF_WAVE)
-dehoog_points_kernel(const ucf_dev_params P, int nt, int nr, int ir0, int nrc, const double* __restrict__ tDv,
-                     const double2* __restrict__ totlap, double* __restrict__ hout, double* __restrict__ dhout,
-                     ucf_stats* st)
+dehoog_points_kernel(const ucf_dev_params P, long long npc, int flat, int per_point, int nr, int ir0, int nrc,
+                     const double* __restrict__ tDv, const double2* __restrict__ totlap, double* __restrict__ hout,
+                     double* __restrict__ dhout, ucf_stats* st)
 {
     const int lane = threadIdx.x;
     const int nz = P.nz;
-    const long long npc = (long long)nt * nrc;
     for (long long lp = blockIdx.x; lp < npc; lp += gridDim.x) {
-        const int it = (int)(lp / nrc), irl = (int)(lp % nrc);
+        int it;
+        size_t obase;
+        if (flat) {
+            it = per_point ? (int)lp : (int)(lp / nr);
+            obase = (size_t)lp;
+        } else {
+            it = (int)(lp / nrc);
+            obase = (size_t)it * nr + ir0 + (int)(lp % nrc);
+        }
         const double tD = tDv[it];
         const double tee = 2.0 * tD;
         const double sigma = P.alpha - P.logtol / (2.0 * tee);
-        const cplx p = cmake(sigma, UCF_PI * lane / tee);
         for (int z = 0; z < nz; z++) {
-            cplx tl = cmake(0.0, 0.0);
-            if (lane < P.np) {
-                const double2 v = totlap[((size_t)lp * nz + z) * P.np + lane];
-                tl = cmake(v.x, v.y);
+            const double2* src = totlap + ((size_t)lp * nz + z) * P.np;
+            double hval, dval;
+            if (P.np <= UCF_WAVE) {
+                const cplx p = cmake(sigma, UCF_PI * lane / tee);
+                cplx tl = cmake(0.0, 0.0);
+                if (lane < P.np) { const double2 v = src[lane]; tl = cmake(v.x, v.y); }
+                hval = dehoog_wave(tl, P.M, P.alpha, P.logtol, tD, tee, lane, st);
+                dval = dehoog_wave(cmul(tl, p), P.M, P.alpha, P.logtol, tD, tee, lane, st) * tD;
+            } else {
+                cplx tl[2], tp[2];
+#pragma unroll
+                for (int g = 0; g < 2; g++) {
+                    const int i = lane + 64 * g;
+                    tl[g] = cmake(0.0, 0.0);
+                    if (i < P.np) { const double2 v = src[i]; tl[g] = cmake(v.x, v.y); }
+                    tp[g] = cmul(tl[g], cmake(sigma, UCF_PI * i / tee));
+                }
+                hval = dehoog_wave2(tl, P.M, P.alpha, P.logtol, tD, tee, lane, st);
+                dval = dehoog_wave2(tp, P.M, P.alpha, P.logtol, tD, tee, lane, st) * tD;
             }
-            const double hval = dehoog_wave(tl, P.M, P.alpha, P.logtol, tD, tee, lane, st);
-            const double dval = dehoog_wave(cmul(tl, p), P.M, P.alpha, P.logtol, tD, tee, lane, st) * tD;
             if (lane == 0) {
-                const size_t o = ((size_t)it * nr + ir0 + irl) * nz + z;
-                hout[o] = hval;
-                dhout[o] = dval;
+                hout[obase * nz + z] = hval;
+                dhout[obase * nz + z] = dval;
             }
         }
     }
@@ -1022,8 +1145,45 @@ int launch_grid_transposed(const ucf_dev_params& dp, int nt, int nr, int ir0, in
     if (ev1) (void)hipEventRecord((hipEvent_t)ev1, s);
     if (hipGetLastError() != hipSuccess) return UCF_ERR_HIP;
     const long long npc = (long long)nt * nrc;
-    hipLaunchKernelGGL(dehoog_points_kernel, dim3((unsigned)(npc > 0x7fffffffLL ? 0x7fffffff : npc)), block, 0, s, dp, nt, nr, ir0,
-                       nrc, d_tD, (const double2*)d_totlap, d_h, d_dh, d_stats);
+    hipLaunchKernelGGL(dehoog_points_kernel, dim3((unsigned)(npc > 0x7fffffffLL ? 0x7fffffff : npc)), block, 0, s, dp, npc, 0, 0,
+                       nr, ir0, nrc, d_tD, (const double2*)d_totlap, d_h, d_dh, d_stats);
+    return hipGetLastError() == hipSuccess ? UCF_OK : UCF_ERR_HIP;
+}
+
+// LAYOUT 2 (2M+1 > 64): (point, 64-sample chunk) work items write the transform, dehoog_points_kernel inverts.
+// Same addressing as launch_points; d_h/d_dh/d_totlap point at this chunk of points.
+int launch_points_chunked(const ucf_dev_params& dp, int npts, int per_point, int nr, int nsv, int svmin, const double* d_tD,
+                          const double* d_rD, const int* d_sv, const double* d_tab, double* d_totlap, double* d_h,
+                          double* d_dh, ucf_stats* d_stats, void* stream)
+{
+    const int fam = family_of(dp);
+    if (fam < 0) return UCF_ERR_UNSUPPORTED;
+    const size_t lds = point_lds_bytes(dp);
+    if (lds > 160 * 1024) return UCF_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    const int nchunk = (dp.np + UCF_WAVE - 1) / UCF_WAVE;
+    const long long nwork = (long long)npts * nchunk;
+    if (nwork > 0x7fffffffLL) return UCF_ERR_BAD_ARGUMENT;
+    dim3 grid((unsigned)nwork), block(UCF_WAVE);
+#define UCF_LAUNCH(F)                                                                                          \
+    do {                                                                                                       \
+        if (lds > 64 * 1024)                                                                                   \
+            (void)hipFuncSetAttribute((const void*)point_kernel<F, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((point_kernel<F, 2>), grid, block, lds, s, dp, (int)nwork, per_point, nr, nsv, svmin, d_tD, d_rD, \
+                           d_sv, (const double2*)d_tab, d_h, d_dh, d_stats, 0, 0, 0, (double2*)d_totlap);      \
+    } while (0)
+    switch (fam) {
+    case 0: UCF_LAUNCH(0); break;
+    case 1: UCF_LAUNCH(1); break;
+    case 2: UCF_LAUNCH(2); break;
+    case 3: UCF_LAUNCH(3); break;
+    case 4: UCF_LAUNCH(4); break;
+    case 5: UCF_LAUNCH(5); break;
+    }
+#undef UCF_LAUNCH
+    if (hipGetLastError() != hipSuccess) return UCF_ERR_HIP;
+    hipLaunchKernelGGL(dehoog_points_kernel, dim3((unsigned)npts), block, 0, s, dp, (long long)npts, 1, per_point, nr, 0, 0, d_tD,
+                       (const double2*)d_totlap, d_h, d_dh, d_stats);
     return hipGetLastError() == hipSuccess ? UCF_OK : UCF_ERR_HIP;
 }
 

@@ -75,6 +75,9 @@ int launch_abscissae(const ucf_dev_params& dp, int nrows, int per_point, int nsv
 int launch_points(const ucf_dev_params& dp, int npts, int per_point, int nr, int nsv, int svmin, const double* d_tD,
                   const double* d_rD, const int* d_sv, const double* d_tab, double* d_h, double* d_dh,
                   ucf_stats* d_stats, void* stream);
+int launch_points_chunked(const ucf_dev_params& dp, int npts, int per_point, int nr, int nsv, int svmin, const double* d_tD,
+                          const double* d_rD, const int* d_sv, const double* d_tab, double* d_totlap, double* d_h,
+                          double* d_dh, ucf_stats* d_stats, void* stream);
 int launch_grid_transposed(const ucf_dev_params& dp, int nt, int nr, int ir0, int nrc, int svmin, const double* d_tD,
                            const double* d_rD, const double* d_tab, double* d_totlap, double* d_h, double* d_dh,
                            ucf_stats* d_stats, void* stream, void* ev0, void* ev1);
@@ -87,6 +90,9 @@ int launch_wynn(int n, int nterms, const double* d_series, double* d_acc, int* d
 int launch_extrap(int n, int R, const double* d_x, const double* d_y, double* d_out, void* stream);
 }
 namespace ucf_fast {
+int launch_points_chunked(const ucf_dev_params& dp, int npts, int per_point, int nr, int nsv, int svmin, const double* d_tD,
+                          const double* d_rD, const int* d_sv, const double* d_tab, double* d_totlap, double* d_h,
+                          double* d_dh, ucf_stats* d_stats, void* stream);
 int launch_grid_transposed(const ucf_dev_params& dp, int nt, int nr, int ir0, int nrc, int svmin, const double* d_tD,
                            const double* d_rD, const double* d_tab, double* d_totlap, double* d_h, double* d_dh,
                            ucf_stats* d_stats, void* stream, void* ev0, void* ev1);
