@@ -277,7 +277,9 @@ def run_deck(deck_path: str, mode: str = "faithful") -> DeckResult:
     if dk.timeseries:
         hobs = screen_average_np(h, dk) * sc
         dobs = screen_average_np(dh, dk) * sc
-        return DeckResult(deck=dk, plan=plan, t=(tD if dk.dimless else t), h=hobs, dh=dobs, raw_h=h, raw_dh=dh)
+        return DeckResult(deck=dk, plan=plan, t=(tD if dk.dimless else t), h=hobs, dh=dobs, raw_h=h, raw_dh=dh,
+                          r_dim=float(r[0]), z_dim=z)
     nt, nr, nz = len(tD), len(rD), len(zD)
     return DeckResult(deck=dk, plan=plan, z=(zD if dk.dimless else z), r=(rD if dk.dimless else r),
-                      h=(h * sc).reshape(nt, nr, nz), dh=(dh * sc).reshape(nt, nr, nz))
+                      h=(h * sc).reshape(nt, nr, nz), dh=(dh * sc).reshape(nt, nr, nz),
+                      r_dim_all=r, z_dim=z, t_dim=float(t[0]))
