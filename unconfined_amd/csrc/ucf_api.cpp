@@ -19,6 +19,9 @@
 
 #include "ucf_plan.h"
 
+// resident-workgroup budget: 256 CUs x 32 single-wave workgroups (only used when the interval areas live in global scratch, nz > 1); UCF_GRID_SLOTS in the environment overrides (tuning)
+int ucf_grid_slots = [] { const char* e = std::getenv("UCF_GRID_SLOTS"); int v = e ? std::atoi(e) : 8192; return v > 0 ? v : 8192; }();
+
 namespace {
 
 thread_local char g_err[512] = "";
@@ -373,6 +376,7 @@ void ucf_plan_destroy(ucf_plan* pl)
     if (pl->d_tables) (void)hipFree(pl->d_tables);
     if (pl->d_work) (void)hipFree(pl->d_work);
     if (pl->d_totlap) (void)hipFree(pl->d_totlap);
+    if (pl->d_glscr) (void)hipFree(pl->d_glscr);
     if (pl->ev0) (void)hipEventDestroy((hipEvent_t)pl->ev0);
     if (pl->ev1) (void)hipEventDestroy((hipEvent_t)pl->ev1);
     std::free(pl->h_j0z); std::free(pl->h_ts_x); std::free(pl->h_ts_w); std::free(pl->h_gl_x); std::free(pl->h_gl_w);
@@ -525,11 +529,23 @@ int ensure_work(ucf_plan* pl, size_t bytes)
     return UCF_OK;
 }
 
+// scratch for the finished interval areas of every resident workgroup
+int ensure_glscr(ucf_plan* pl, int nz)
+{
+    const size_t need = (size_t)UCF_GRID_SLOTS * pl->P.nacc * nz * UCF_WAVE * 2 * sizeof(double);
+    if (pl->glscr_bytes >= need) return UCF_OK;
+    if (pl->d_glscr) { (void)hipDeviceSynchronize(); (void)hipFree(pl->d_glscr); pl->d_glscr = nullptr; pl->glscr_bytes = 0; }
+    if (hipMalloc((void**)&pl->d_glscr, need) != hipSuccess) return fail(UCF_ERR_NOMEM, "hipMalloc of %zu area-scratch bytes failed", need);
+    pl->glscr_bytes = need;
+    return UCF_OK;
+}
+
 int launch_points_any(ucf_plan* pl, const ucf_dev_params& dp, int npts, int per_point, int nr, int nsv, int svmin,
                       const double* d_tD, const double* d_rD, const int* d_sv, double* d_h, double* d_dh,
                       ucf_stats* d_stats, void* stream)
 {
-    int rc;
+    int rc = ensure_glscr(pl, dp.nz);
+    if (rc) return rc;
     if (pl->D.np > UCF_WAVE) {
         // more Laplace samples than lanes: (point, 64-sample chunk) work items + separate inversion kernel
         const size_t need = (size_t)npts * dp.nz * pl->D.np * 2 * sizeof(double);
@@ -539,12 +555,12 @@ int launch_points_any(ucf_plan* pl, const ucf_dev_params& dp, int npts, int per_
             pl->totlap_bytes = need;
         }
         rc = (pl->mode == 1)
-                 ? ucf_fast::launch_points_chunked(dp, npts, per_point, nr, nsv, svmin, d_tD, d_rD, d_sv, pl->d_work, pl->d_totlap, d_h, d_dh, d_stats, stream)
-                 : ucf_faithful::launch_points_chunked(dp, npts, per_point, nr, nsv, svmin, d_tD, d_rD, d_sv, pl->d_work, pl->d_totlap, d_h, d_dh, d_stats, stream);
+                 ? ucf_fast::launch_points_chunked(dp, npts, per_point, nr, nsv, svmin, d_tD, d_rD, d_sv, pl->d_work, pl->d_totlap, d_h, d_dh, d_stats, stream, pl->d_glscr)
+                 : ucf_faithful::launch_points_chunked(dp, npts, per_point, nr, nsv, svmin, d_tD, d_rD, d_sv, pl->d_work, pl->d_totlap, d_h, d_dh, d_stats, stream, pl->d_glscr);
     } else {
         rc = (pl->mode == 1)
-                 ? ucf_fast::launch_points(dp, npts, per_point, nr, nsv, svmin, d_tD, d_rD, d_sv, pl->d_work, d_h, d_dh, d_stats, stream)
-                 : ucf_faithful::launch_points(dp, npts, per_point, nr, nsv, svmin, d_tD, d_rD, d_sv, pl->d_work, d_h, d_dh, d_stats, stream);
+                 ? ucf_fast::launch_points(dp, npts, per_point, nr, nsv, svmin, d_tD, d_rD, d_sv, pl->d_work, d_h, d_dh, d_stats, stream, pl->d_glscr)
+                 : ucf_faithful::launch_points(dp, npts, per_point, nr, nsv, svmin, d_tD, d_rD, d_sv, pl->d_work, d_h, d_dh, d_stats, stream, pl->d_glscr);
     }
     if (rc == UCF_ERR_UNSUPPORTED) return fail(rc, "this model / size combination has no kernel (model %d, LDS limit)", dp.model);
     if (rc) return fail(rc, "kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
@@ -589,6 +605,8 @@ int ucf_drawdown_grid_device(ucf_plan* pl, int nt, const double* d_tD, const int
                 return fail(UCF_ERR_NOMEM, "hipMalloc of %zu transform-workspace bytes failed", per_radius * nrc);
             pl->totlap_bytes = per_radius * nrc;
         }
+        rc = ensure_glscr(pl, nz);
+        if (rc) return rc;
         // timing brackets the transform kernel of a single-chunk call (the dominant kernel of the path)
         void* tev0 = nullptr; void* tev1 = nullptr;
         pl->ev_valid = 0;
@@ -601,8 +619,8 @@ int ucf_drawdown_grid_device(ucf_plan* pl, int nt, const double* d_tD, const int
         for (int ir0 = 0; ir0 < nr; ir0 += nrc) {
             const int n = (nr - ir0 < nrc) ? nr - ir0 : nrc;
             rc = (pl->mode == 1)
-                     ? ucf_fast::launch_grid_transposed(dp, nt, nr, ir0, n, svmin, d_tD, d_rD, pl->d_work, pl->d_totlap, d_h, d_dh, d_stats, stream, tev0, tev1)
-                     : ucf_faithful::launch_grid_transposed(dp, nt, nr, ir0, n, svmin, d_tD, d_rD, pl->d_work, pl->d_totlap, d_h, d_dh, d_stats, stream, tev0, tev1);
+                     ? ucf_fast::launch_grid_transposed(dp, nt, nr, ir0, n, svmin, d_tD, d_rD, pl->d_work, pl->d_totlap, d_h, d_dh, d_stats, stream, tev0, tev1, pl->d_glscr)
+                     : ucf_faithful::launch_grid_transposed(dp, nt, nr, ir0, n, svmin, d_tD, d_rD, pl->d_work, pl->d_totlap, d_h, d_dh, d_stats, stream, tev0, tev1, pl->d_glscr);
             if (rc == UCF_ERR_UNSUPPORTED) return fail(rc, "this model / size combination has no kernel (model %d, LDS limit)", dp.model);
             if (rc) return fail(rc, "kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
         }

@@ -43,10 +43,11 @@ UCF_DEV void stat_add(long long* ctr, bool pred)
 typedef double2 lds_c;   // one complex per lane per slot
 UCF_DEV cplx lds_ld(const lds_c* base, int slot, int lane) { lds_c v = base[slot * UCF_WAVE + lane]; return cmake(v.x, v.y); }
 UCF_DEV void lds_st(lds_c* base, int slot, int lane, cplx z) { base[slot * UCF_WAVE + lane] = make_double2(z.re, z.im); }
-// scratch columns hold one half-wave (32 lanes) per slot: the per-lane tails (Neville, Wynn) run on
-// one half-wave at a time, which halves their LDS footprint at < 2 % of the point's time
-UCF_DEV cplx scr_ld(const lds_c* base, int slot, int lane) { lds_c v = base[slot * (UCF_WAVE / 2) + (lane & 31)]; return cmake(v.x, v.y); }
-UCF_DEV void scr_st(lds_c* base, int slot, int lane, cplx z) { base[slot * (UCF_WAVE / 2) + (lane & 31)] = make_double2(z.re, z.im); }
+// scratch columns hold UCF_PART lanes per slot: the per-lane tails (Neville, Wynn) run on one
+// quarter-wave at a time, which quarters their LDS footprint at ~2 % of the point's time
+#define UCF_PART 16
+UCF_DEV cplx scr_ld(const lds_c* base, int slot, int lane) { lds_c v = base[slot * UCF_PART + (lane & (UCF_PART - 1))]; return cmake(v.x, v.y); }
+UCF_DEV void scr_st(lds_c* base, int slot, int lane, cplx z) { base[slot * UCF_PART + (lane & (UCF_PART - 1))] = make_double2(z.re, z.im); }
 
 #if UCF_FAST
 // 1/z without exponent scaling (|z| well inside [1e-150, 1e150])
@@ -591,23 +592,34 @@ UCF_DEV double dehoog_wave2(const cplx (&f)[2], int M, double alpha, double logt
 }
 
 // ------------------------------------------------------------- integration.f90:125-189
-// Per-lane Wynn-epsilon on LDS columns.  colA[(i*strideA)][lane] holds series(i+1) on
-// entry (overwritten by the even epsilon columns); colB is half-wave scratch (odd columns).
+// Per-lane Wynn-epsilon on two quarter-wave LDS scratch columns: colA[i] holds series(i+1) on entry
+// (overwritten by the even epsilon columns), colB the odd columns.
 // status: 0 ok, 1 truncated, 2 sentinel, 3 early exit.
 template <bool CUR_IS_A>
-UCF_DEV bool wynn_column(lds_c* colA, int strideA, lds_c* colB, int count, int lane, cplx* acc)
+UCF_DEV bool wynn_column(lds_c* colA, lds_c* colB, int count, int lane, cplx* acc)
 {
     // new(m) = prev(m+1) + 1/(cur(m+1) - cur(m)), m = 1..count; new column overwrites prev storage
+    lds_c* cur = CUR_IS_A ? colA : colB;
+    lds_c* prv = CUR_IS_A ? colB : colA;
     for (int m = 1; m <= count; m++) {
-        const cplx hi = CUR_IS_A ? lds_ld(colA, m * strideA, lane) : scr_ld(colB, m, lane);
-        const cplx lo = CUR_IS_A ? lds_ld(colA, (m - 1) * strideA, lane) : scr_ld(colB, m - 1, lane);
+        const cplx hi = scr_ld(cur, m, lane);
+        const cplx lo = scr_ld(cur, m - 1, lane);
         const cplx denom = csub(hi, lo);
-        if (cabs_(denom) > UCF_EPS) {                                                           // :172
-            const cplx pv = CUR_IS_A ? scr_ld(colB, m, lane) : lds_ld(colA, m * strideA, lane);
-            const cplx nw = cadd(pv, rdiv(1.0, denom));                                         // :173
-            if (CUR_IS_A) scr_st(colB, m - 1, lane, nw);
-            else lds_st(colA, (m - 1) * strideA, lane, nw);
+#if UCF_FAST
+        // |denom| > eps  <=>  |denom|^2 > eps^2 (no hypot), and 1/denom = conj(denom)/|denom|^2 reuses it
+        const double d2 = __builtin_fma(denom.re, denom.re, denom.im * denom.im);
+        if (d2 > UCF_EPS * UCF_EPS && d2 < 1.0e300) {
+            const double r = fast_rcp(d2);
+            const cplx pv = scr_ld(prv, m, lane);
+            scr_st(prv, m - 1, lane, cmake(__builtin_fma(denom.re, r, pv.re), __builtin_fma(-denom.im, r, pv.im)));
+        } else if (cabs_(denom) > UCF_EPS) {                 // huge or non-finite difference: exact reference path
+            scr_st(prv, m - 1, lane, cadd(scr_ld(prv, m, lane), rdiv(1.0, denom)));
         } else {
+#else
+        if (cabs_(denom) > UCF_EPS) {                                                           // :172
+            scr_st(prv, m - 1, lane, cadd(scr_ld(prv, m, lane), rdiv(1.0, denom)));             // :173
+        } else {
+#endif
             *acc = hi;                                                                          // :175
             return true;
         }
@@ -615,20 +627,20 @@ UCF_DEV bool wynn_column(lds_c* colA, int strideA, lds_c* colB, int count, int l
     return false;
 }
 
-UCF_DEV cplx wynn_lane(lds_c* colA, int strideA, lds_c* colB, int nin, int lane, int* status)
+UCF_DEV cplx wynn_lane(lds_c* colA, lds_c* colB, int nin, int lane, int* status)
 {
     int ns = nin;
     int stat = 0;
     cplx run = cmake(0.0, 0.0);
     for (int i = 1; i <= nin; i++) {                                                            // :140-163
-        cplx s = lds_ld(colA, (i - 1) * strideA, lane);
+        cplx s = scr_ld(colA, i - 1, lane);
         if (!c_is_finite(s)) {
             ns = i - 1;
             stat = (ns < 4) ? 2 : 1;
             break;
         }
         run = (i == 1) ? s : cadd(run, s);
-        lds_st(colA, (i - 1) * strideA, lane, run);
+        scr_st(colA, i - 1, lane, run);
     }
     if (stat == 2) {
         *status = 2;
@@ -639,11 +651,10 @@ UCF_DEV cplx wynn_lane(lds_c* colA, int strideA, lds_c* colB, int nin, int lane,
     bool done = false;
     for (int j = 0; j <= ns - 2 && !done; j++) {                                                // :169-181
         const int count = ns - (j + 1);
-        done = (j & 1) ? wynn_column<false>(colA, strideA, colB, count, lane, &acc)
-                       : wynn_column<true>(colA, strideA, colB, count, lane, &acc);
+        done = (j & 1) ? wynn_column<false>(colA, colB, count, lane, &acc) : wynn_column<true>(colA, colB, count, lane, &acc);
         if (done) stat = 3;
     }
-    if (!done) acc = lds_ld(colA, 1 * strideA, lane);   // eps(2,ns-2) [ns even] or eps(2,ns-3) [ns odd]: both even columns
+    if (!done) acc = scr_ld(colA, 1, lane);   // eps(2,ns-2) [ns even] or eps(2,ns-3) [ns odd]: both even columns
     *status = stat;
     return acc;
 }
@@ -733,16 +744,21 @@ __global__ void __launch_bounds__(UCF_WAVE, 2)
 point_kernel(const ucf_dev_params P, int npts, int per_point, int nr, int nsv, int svmin,
              const double* __restrict__ tDv, const double* __restrict__ rDv, const int* __restrict__ svv,
              const double2* __restrict__ tab, double* __restrict__ hout, double* __restrict__ dhout, ucf_stats* st,
-             int nt, int ir0, int nrc, double2* __restrict__ totlap)
+             int nt, int ir0, int nrc, double2* __restrict__ totlap, double2* __restrict__ glscr)
 {
     extern __shared__ lds_c lds[];
     const int lane = threadIdx.x;
     const int nz = P.nz, R = P.R, nacc = P.nacc, N = P.N, ngl = P.ngl;
     const int nabs = N + nacc * ngl;
-    lds_c* accTS = lds;                                     // [R][nz]
-    lds_c* accGL = lds + (size_t)R * nz * UCF_WAVE;         // [nacc][nz]
-    lds_c* scr = accGL + (size_t)nacc * nz * UCF_WAVE;      // [max(nacc,R)] half-wave slots
-    lds_c* fdbuf = scr + (size_t)(nacc > R ? nacc : R) * (UCF_WAVE / 2);
+    lds_c* accTS = lds;                                     // [R][nz]  level sums
+    lds_c* accCur = lds + (size_t)R * nz * UCF_WAVE;        // [nz]     area of the J0 interval being integrated
+    lds_c* scr = accCur + (size_t)nz * UCF_WAVE;            // [max(2 nacc, R)] quarter-wave slots: Wynn columns / Neville
+    lds_c* accGL = scr + (size_t)(2 * nacc > R ? 2 * nacc : R) * UCF_PART;   // [nacc][nz] finished areas (if kept in LDS)
+    // finished interval areas: in LDS while that does not cost occupancy (nz = 1), else in an L2-resident
+    // global scratch slot of this (then persistent, grid-strided) workgroup: [nacc][nz][64] complex
+    const bool areas_lds = (glscr == nullptr);
+    lds_c* fdbuf = accGL + (areas_lds ? (size_t)nacc * nz * UCF_WAVE : 0);
+    double2* __restrict__ areas = areas_lds ? nullptr : glscr + (size_t)blockIdx.x * nacc * nz * UCF_WAVE;
 
     bool need_lay1 = false;
     for (int z = 0; z < nz; z++) need_lay1 |= (P.zLay[z] == 1);
@@ -788,7 +804,7 @@ point_kernel(const ucf_dev_params P, int npts, int per_point, int nr, int nsv, i
 #endif
         const cplx lane_aux = (FAMILY == 5) ? hstorage_A0(P, p) : cmake(0.0, 0.0);
 
-        for (int s = 0; s < (R + nacc) * nz; s++) lds_st(lds, s, lane, cmake(0.0, 0.0));
+        for (int s = 0; s < (R + 1) * nz; s++) lds_st(lds, s, lane, cmake(0.0, 0.0));
 
         // one pass over all abscissae: n < N tanh-sinh on [0,arg] feeding every Richardson level
         // (driver.f90:129-157); n >= N Gauss-Lobatto between successive J0 zeros (:187-203)
@@ -809,14 +825,16 @@ point_kernel(const ucf_dev_params P, int npts, int per_point, int nr, int nsv, i
             } else {
                 const int g = n - N;
                 const int jj = g / ngl, m = g - jj * ngl;
-                const int slot = jj * nz + z;
-                cplx acc = cadd(lds_ld(accGL, slot, lane), cscale(val, P.gl_w[m]));             // :201-202
+                cplx acc = cadd(lds_ld(accCur, z, lane), cscale(val, P.gl_w[m]));               // :201-202
                 if (m == ngl - 1) {
                     const double lob = P.j0z[sv + jj - 1] / rD;
                     const double hib = P.j0z[sv + jj] / rD;
                     acc = rscale((hib - lob) / 2.0, acc);
+                    if (areas_lds) lds_st(accGL, jj * nz + z, lane, acc);
+                    else areas[(size_t)(jj * nz + z) * UCF_WAVE + lane] = make_double2(acc.re, acc.im);
+                    acc = cmake(0.0, 0.0);
                 }
-                lds_st(accGL, slot, lane, acc);
+                lds_st(accCur, z, lane, acc);
             }
         };
         int n = 0;
@@ -846,14 +864,26 @@ point_kernel(const ucf_dev_params P, int npts, int per_point, int nr, int nsv, i
                 lds_st(accTS, slot, lane, rscale(arg / 2.0, lds_ld(accTS, slot, lane)));        // :135,154
             }
             bool any = false;
-            for (int jj = 0; jj < nacc; jj++) any |= (cabs_(lds_ld(accGL, jj * nz + z, lane)) > 0.0);   // :209
             cplx finint = lds_ld(accTS, z, lane);
             cplx infint = cmake(0.0, 0.0);
             int wst = 0;
-            for (int half = 0; half < 2; half++) {
-                if ((lane >> 5) == half) {
+            for (int part = 0; part < UCF_WAVE / UCF_PART; part++) {
+                if ((lane / UCF_PART) == part) {
                     if (R > 1) finint = extrap_lane(accTS + (size_t)z * UCF_WAVE, nz, scr, P.hv, R, lane);
-                    if (any) infint = wynn_lane(accGL + (size_t)z * UCF_WAVE, nz, scr, nacc, lane, &wst);
+                    lds_c* colA = scr;
+                    lds_c* colB = scr + (size_t)nacc * UCF_PART;
+                    for (int jj = 0; jj < nacc; jj++) {
+                        cplx ar;
+                        if (areas_lds) {
+                            ar = lds_ld(accGL, jj * nz + z, lane);
+                        } else {
+                            const double2 v = areas[(size_t)(jj * nz + z) * UCF_WAVE + lane];
+                            ar = cmake(v.x, v.y);
+                        }
+                        any |= (cabs_(ar) > 0.0);                                               // :209
+                        scr_st(colA, jj, lane, ar);
+                    }
+                    if (any) infint = wynn_lane(colA, colB, nacc, lane, &wst);
                 }
             }
             if (st) {
@@ -1011,14 +1041,16 @@ wynn_kernel(int n, int nterms, const double* __restrict__ series, double* __rest
     const int lane = threadIdx.x;
     const int i = blockIdx.x * UCF_WAVE + lane;
     lds_c* colA = lds;
-    lds_c* colB = lds + (size_t)nterms * UCF_WAVE;
+    lds_c* colB = lds + (size_t)nterms * UCF_PART;
     const int ii = i < n ? i : n - 1;
-    for (int k = 0; k < nterms; k++)
-        lds_st(colA, k, lane, cmake(series[((size_t)ii * nterms + k) * 2], series[((size_t)ii * nterms + k) * 2 + 1]));
     int stt = 0;
     cplx r = cmake(0.0, 0.0);
-    for (int half = 0; half < 2; half++)
-        if ((lane >> 5) == half) r = wynn_lane(colA, 1, colB, nterms, lane, &stt);
+    for (int part = 0; part < UCF_WAVE / UCF_PART; part++)
+        if ((lane / UCF_PART) == part) {
+            for (int k = 0; k < nterms; k++)
+                scr_st(colA, k, lane, cmake(series[((size_t)ii * nterms + k) * 2], series[((size_t)ii * nterms + k) * 2 + 1]));
+            r = wynn_lane(colA, colB, nterms, lane, &stt);
+        }
     if (i < n) {
         acc[2 * i] = r.re;
         acc[2 * i + 1] = r.im;
@@ -1038,8 +1070,8 @@ extrap_kernel(int n, int R, const double* __restrict__ x, const double* __restri
     for (int k = 0; k < R; k++)
         lds_st(colC, k, lane, cmake(y[((size_t)ii * R + k) * 2], y[((size_t)ii * R + k) * 2 + 1]));
     cplx r = cmake(0.0, 0.0);
-    for (int half = 0; half < 2; half++)
-        if ((lane >> 5) == half) r = extrap_lane(colC, 1, colD, x, R, lane);
+    for (int part = 0; part < UCF_WAVE / UCF_PART; part++)
+        if ((lane / UCF_PART) == part) r = extrap_lane(colC, 1, colD, x, R, lane);
     if (i < n) {
         out[2 * i] = r.re;
         out[2 * i + 1] = r.im;
@@ -1060,9 +1092,16 @@ static inline int family_of(const ucf_dev_params& dp)
     }
 }
 
+// finished interval areas stay in LDS while the footprint still admits 8 single-wave workgroups per CU
+static inline bool areas_in_lds(const ucf_dev_params& dp)
+{
+    const size_t with_areas = ((size_t)(dp.R + 1 + dp.nacc) * dp.nz * UCF_WAVE + (size_t)(2 * dp.nacc > dp.R ? 2 * dp.nacc : dp.R) * UCF_PART) * sizeof(lds_c);
+    return with_areas <= 20 * 1024;
+}
+
 static inline size_t point_lds_bytes(const ucf_dev_params& dp)
 {
-    size_t bytes = ((size_t)(dp.R + dp.nacc) * dp.nz * UCF_WAVE + (size_t)(dp.nacc > dp.R ? dp.nacc : dp.R) * (UCF_WAVE / 2)) * sizeof(lds_c);
+    size_t bytes = ((size_t)(dp.R + 1 + (areas_in_lds(dp) ? dp.nacc : 0)) * dp.nz * UCF_WAVE + (size_t)(2 * dp.nacc > dp.R ? 2 * dp.nacc : dp.R) * UCF_PART) * sizeof(lds_c);
 #if !UCF_FAST
     if (family_of(dp) == 4) bytes += 2 * (size_t)dp.order * UCF_WAVE * sizeof(lds_c);
 #endif
@@ -1084,20 +1123,22 @@ int launch_abscissae(const ucf_dev_params& dp, int nrows, int per_point, int nsv
 
 int launch_points(const ucf_dev_params& dp, int npts, int per_point, int nr, int nsv, int svmin, const double* d_tD,
                   const double* d_rD, const int* d_sv, const double* d_tab, double* d_h, double* d_dh,
-                  ucf_stats* d_stats, void* stream)
+                  ucf_stats* d_stats, void* stream, double* d_glscr)
 {
     const int fam = family_of(dp);
     if (fam < 0) return UCF_ERR_UNSUPPORTED;
     const size_t lds = point_lds_bytes(dp);
     if (lds > 160 * 1024) return UCF_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
-    dim3 grid(npts), block(UCF_WAVE);
+    const bool al = areas_in_lds(dp);
+    if (al) d_glscr = nullptr;
+    dim3 grid((al || npts < UCF_GRID_SLOTS) ? npts : UCF_GRID_SLOTS), block(UCF_WAVE);
 #define UCF_LAUNCH(F)                                                                                          \
     do {                                                                                                       \
         if (lds > 64 * 1024)                                                                                   \
             (void)hipFuncSetAttribute((const void*)point_kernel<F, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL((point_kernel<F, 0>), grid, block, lds, s, dp, npts, per_point, nr, nsv, svmin, d_tD, d_rD, d_sv, \
-                           (const double2*)d_tab, d_h, d_dh, d_stats, 0, 0, 0, (double2*)nullptr);            \
+                           (const double2*)d_tab, d_h, d_dh, d_stats, 0, 0, 0, (double2*)nullptr, (double2*)d_glscr); \
     } while (0)
     switch (fam) {
     case 0: UCF_LAUNCH(0); break;
@@ -1114,7 +1155,7 @@ int launch_points(const ucf_dev_params& dp, int npts, int per_point, int nr, int
 // LAYOUT 1 (lane = time): transform kernel over (radius chunk x time tiles x Laplace index), then de Hoog
 int launch_grid_transposed(const ucf_dev_params& dp, int nt, int nr, int ir0, int nrc, int svmin, const double* d_tD,
                            const double* d_rD, const double* d_tab, double* d_totlap, double* d_h, double* d_dh,
-                           ucf_stats* d_stats, void* stream, void* ev0, void* ev1)
+                           ucf_stats* d_stats, void* stream, void* ev0, void* ev1, double* d_glscr)
 {
     const int fam = family_of(dp);
     if (fam < 0) return UCF_ERR_UNSUPPORTED;
@@ -1125,13 +1166,15 @@ int launch_grid_transposed(const ucf_dev_params& dp, int nt, int nr, int ir0, in
     const int ntiles = (nt + UCF_WAVE - 1) / UCF_WAVE;
     const long long nwork = (long long)nrc * ntiles * dp.np;
     if (nwork > 0x7fffffffLL) return UCF_ERR_BAD_ARGUMENT;
-    dim3 grid((unsigned)nwork), block(UCF_WAVE);
+    const bool al = areas_in_lds(dp);
+    if (al) d_glscr = nullptr;
+    dim3 grid((unsigned)((al || nwork < UCF_GRID_SLOTS) ? nwork : UCF_GRID_SLOTS)), block(UCF_WAVE);
 #define UCF_LAUNCH(F)                                                                                          \
     do {                                                                                                       \
         if (lds > 64 * 1024)                                                                                   \
             (void)hipFuncSetAttribute((const void*)point_kernel<F, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL((point_kernel<F, 1>), grid, block, lds, s, dp, (int)nwork, 0, nr, 1, svmin, d_tD, d_rD,           \
-                           (const int*)nullptr, (const double2*)d_tab, d_h, d_dh, d_stats, nt, ir0, nrc, (double2*)d_totlap); \
+                           (const int*)nullptr, (const double2*)d_tab, d_h, d_dh, d_stats, nt, ir0, nrc, (double2*)d_totlap, (double2*)d_glscr); \
     } while (0)
     switch (fam) {
     case 0: UCF_LAUNCH(0); break;
@@ -1154,7 +1197,7 @@ int launch_grid_transposed(const ucf_dev_params& dp, int nt, int nr, int ir0, in
 // Same addressing as launch_points; d_h/d_dh/d_totlap point at this chunk of points.
 int launch_points_chunked(const ucf_dev_params& dp, int npts, int per_point, int nr, int nsv, int svmin, const double* d_tD,
                           const double* d_rD, const int* d_sv, const double* d_tab, double* d_totlap, double* d_h,
-                          double* d_dh, ucf_stats* d_stats, void* stream)
+                          double* d_dh, ucf_stats* d_stats, void* stream, double* d_glscr)
 {
     const int fam = family_of(dp);
     if (fam < 0) return UCF_ERR_UNSUPPORTED;
@@ -1164,13 +1207,15 @@ int launch_points_chunked(const ucf_dev_params& dp, int npts, int per_point, int
     const int nchunk = (dp.np + UCF_WAVE - 1) / UCF_WAVE;
     const long long nwork = (long long)npts * nchunk;
     if (nwork > 0x7fffffffLL) return UCF_ERR_BAD_ARGUMENT;
-    dim3 grid((unsigned)nwork), block(UCF_WAVE);
+    const bool al = areas_in_lds(dp);
+    if (al) d_glscr = nullptr;
+    dim3 grid((unsigned)((al || nwork < UCF_GRID_SLOTS) ? nwork : UCF_GRID_SLOTS)), block(UCF_WAVE);
 #define UCF_LAUNCH(F)                                                                                          \
     do {                                                                                                       \
         if (lds > 64 * 1024)                                                                                   \
             (void)hipFuncSetAttribute((const void*)point_kernel<F, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL((point_kernel<F, 2>), grid, block, lds, s, dp, (int)nwork, per_point, nr, nsv, svmin, d_tD, d_rD, \
-                           d_sv, (const double2*)d_tab, d_h, d_dh, d_stats, 0, 0, 0, (double2*)d_totlap);      \
+                           d_sv, (const double2*)d_tab, d_h, d_dh, d_stats, 0, 0, 0, (double2*)d_totlap, (double2*)d_glscr); \
     } while (0)
     switch (fam) {
     case 0: UCF_LAUNCH(0); break;
@@ -1228,14 +1273,14 @@ int launch_dehoog(int n, int M, double alpha, double logtol, const double* d_t, 
 }
 int launch_wynn(int n, int nterms, const double* d_series, double* d_acc, int* d_status, void* stream)
 {
-    const size_t lds = ((size_t)nterms * UCF_WAVE + (size_t)nterms * (UCF_WAVE / 2)) * sizeof(lds_c);
+    const size_t lds = 2 * (size_t)nterms * UCF_PART * sizeof(lds_c);
     hipLaunchKernelGGL(wynn_kernel, dim3((n + UCF_WAVE - 1) / UCF_WAVE), dim3(UCF_WAVE), lds, (hipStream_t)stream, n,
                        nterms, d_series, d_acc, d_status);
     return hipGetLastError() == hipSuccess ? UCF_OK : UCF_ERR_HIP;
 }
 int launch_extrap(int n, int R, const double* d_x, const double* d_y, double* d_out, void* stream)
 {
-    const size_t lds = ((size_t)R * UCF_WAVE + (size_t)R * (UCF_WAVE / 2)) * sizeof(lds_c);
+    const size_t lds = ((size_t)R * UCF_WAVE + (size_t)R * UCF_PART) * sizeof(lds_c);
     hipLaunchKernelGGL(extrap_kernel, dim3((n + UCF_WAVE - 1) / UCF_WAVE), dim3(UCF_WAVE), lds, (hipStream_t)stream, n,
                        R, d_x, d_y, d_out);
     return hipGetLastError() == hipSuccess ? UCF_OK : UCF_ERR_HIP;

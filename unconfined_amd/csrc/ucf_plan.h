@@ -4,6 +4,8 @@
 
 #define UCF_WAVE 64
 #define UCF_MAX_R 16
+extern int ucf_grid_slots;     /* workgroups per launch (grid-stride over the work items); each owns a scratch slot */
+#define UCF_GRID_SLOTS ucf_grid_slots
 
 // Everything a kernel needs, passed by value as one kernel argument (lives in
 // SGPRs / the scalar cache: it is wave-uniform).  Table pointers are device
@@ -65,6 +67,9 @@ struct ucf_plan {
     // LAYOUT 1 workspace: accelerated transform totlap(t, r, z, m), 16 B each
     double* d_totlap;
     size_t totlap_bytes;
+    // finished J0-interval areas of the resident workgroups: [UCF_GRID_SLOTS][nacc][nz][64] complex
+    double* d_glscr;
+    size_t glscr_bytes;
 };
 
 // launchers implemented in ucf_kernels.hip (one set per build flavour)
@@ -74,13 +79,13 @@ int launch_abscissae(const ucf_dev_params& dp, int nrows, int per_point, int nsv
                      const int* d_sv, double* d_tab, void* stream);
 int launch_points(const ucf_dev_params& dp, int npts, int per_point, int nr, int nsv, int svmin, const double* d_tD,
                   const double* d_rD, const int* d_sv, const double* d_tab, double* d_h, double* d_dh,
-                  ucf_stats* d_stats, void* stream);
+                  ucf_stats* d_stats, void* stream, double* d_glscr);
 int launch_points_chunked(const ucf_dev_params& dp, int npts, int per_point, int nr, int nsv, int svmin, const double* d_tD,
                           const double* d_rD, const int* d_sv, const double* d_tab, double* d_totlap, double* d_h,
-                          double* d_dh, ucf_stats* d_stats, void* stream);
+                          double* d_dh, ucf_stats* d_stats, void* stream, double* d_glscr);
 int launch_grid_transposed(const ucf_dev_params& dp, int nt, int nr, int ir0, int nrc, int svmin, const double* d_tD,
                            const double* d_rD, const double* d_tab, double* d_totlap, double* d_h, double* d_dh,
-                           ucf_stats* d_stats, void* stream, void* ev0, void* ev1);
+                           ucf_stats* d_stats, void* stream, void* ev0, void* ev1, double* d_glscr);
 int launch_samples(const ucf_dev_params& dp, int n_a, const double* d_a, double rD, const double* d_p, double* d_fp,
                    void* stream);
 int launch_bessel(int n, const double* d_z, double* d_k, int* d_ierr, void* stream);
@@ -92,13 +97,13 @@ int launch_extrap(int n, int R, const double* d_x, const double* d_y, double* d_
 namespace ucf_fast {
 int launch_points_chunked(const ucf_dev_params& dp, int npts, int per_point, int nr, int nsv, int svmin, const double* d_tD,
                           const double* d_rD, const int* d_sv, const double* d_tab, double* d_totlap, double* d_h,
-                          double* d_dh, ucf_stats* d_stats, void* stream);
+                          double* d_dh, ucf_stats* d_stats, void* stream, double* d_glscr);
 int launch_grid_transposed(const ucf_dev_params& dp, int nt, int nr, int ir0, int nrc, int svmin, const double* d_tD,
                            const double* d_rD, const double* d_tab, double* d_totlap, double* d_h, double* d_dh,
-                           ucf_stats* d_stats, void* stream, void* ev0, void* ev1);
+                           ucf_stats* d_stats, void* stream, void* ev0, void* ev1, double* d_glscr);
 int launch_points(const ucf_dev_params& dp, int npts, int per_point, int nr, int nsv, int svmin, const double* d_tD,
                   const double* d_rD, const int* d_sv, const double* d_tab, double* d_h, double* d_dh,
-                  ucf_stats* d_stats, void* stream);
+                  ucf_stats* d_stats, void* stream, double* d_glscr);
 int launch_samples(const ucf_dev_params& dp, int n_a, const double* d_a, double rD, const double* d_p, double* d_fp,
                    void* stream);
 }
