@@ -173,6 +173,15 @@ int ucf_drawdown_grid_device(ucf_plan* plan, int nt, const double* d_tD, const i
                              int nz, const double* zD, const int* zLay, double* d_h, double* d_dh,
                              ucf_stats* d_stats, void* stream);
 
+/* Parameter-batched evaluation for inversion / fitting (the tool's real use,
+ * reference README.md:45-56): the SAME observation points -- dimensional times t[npts], radii r[npts],
+ * depths z[nz] (z up from the aquifer base) -- under nplans parameter sets.  Each plan
+ * non-dimensionalises with its own Lc, Tc (driver_io.f90:531-567), gets its own layers and split vector,
+ * and runs on one of a small pool of HIP streams so that the small launches overlap.
+ * h, dh: [nplans][npts][nz]; dimensional (x Hc of each plan) unless dimensionless != 0. */
+int ucf_drawdown_multi(ucf_plan* const* plans, int nplans, int npts, const double* t, const double* r,
+                       int nz, const double* z, int dimensionless, double* h, double* dh);
+
 /* driver.f90:234-243 (quirk Q2: not a textbook trapezoid) */
 int ucf_screen_average(int npts, int zOrd, const double* h, double* havg);
 

@@ -368,6 +368,26 @@ def test_edge_cases(engine, oracle, oracle_quad):
         assert np.array_equal(hg[:, 0, :], h), M            # grid (lane = time) and per-point entries: same bits
 
 
+def test_parameter_batched_sweep(engine):
+    """f4: the same observation points under 12 parameter sets in one call == 12 single-plan calls"""
+    from unconfined_amd.abi import params_from_deck
+    dk, ts, P0 = load_deck("neuman74_partpen")
+    plans = []
+    for i in range(12):
+        d = dk.replace(Kr=dk.Kr * (0.5 + 0.1 * i), Sy=dk.Sy * (0.8 + 0.03 * i), kappa=dk.kappa * (0.7 + 0.05 * i))
+        plans.append(engine.Plan(params_from_deck(d), mode="fast"))
+    t = 10.0 ** np.linspace(-1, 4, 37); r = np.full(37, 85.1); r[::3] = 30.0
+    z = np.array([145.7, 100.0])
+    h, dh = engine.drawdown_multi(plans, t, r, z)
+    assert h.shape == (12, 37, 2) and np.isfinite(h).all()
+    for k, pl in enumerate(plans):
+        D = pl.derived
+        tD, rD, zD = t / D.Tc, r / D.Lc, z / D.Lc
+        h1, dh1 = pl.drawdown(tD, rD, pl.split_vector(tD), zD, pl.zlay(zD))
+        assert np.array_equal(h[k], h1 * D.Hc) and np.array_equal(dh[k], dh1 * D.Hc), k
+    assert np.abs(h[0] - h[11]).max() > 1e-3        # the parameter sets do differ
+
+
 def test_smoke_entry():
     import __graft_entry__ as g
     g.smoke()

@@ -730,6 +730,60 @@ int ucf_drawdown_grid(ucf_plan* pl, int nt, const double* tD, const int* sv, int
     return UCF_OK;
 }
 
+int ucf_drawdown_multi(ucf_plan* const* plans, int nplans, int npts, const double* t, const double* r,
+                       int nz, const double* z, int dimensionless, double* h, double* dh)
+{
+    if (!plans || nplans < 1) return fail(UCF_ERR_BAD_ARGUMENT, "no plans");
+    if (npts < 0 || nz < 1 || nz > UCF_MAX_NZ) return fail(UCF_ERR_BAD_ARGUMENT, "bad sizes");
+    if (npts == 0) return UCF_OK;
+    if (!t || !r || !z || !h || !dh) return fail(UCF_ERR_BAD_ARGUMENT, "NULL array");
+    for (int k = 0; k < nplans; k++) if (!plans[k]) return fail(UCF_ERR_BAD_ARGUMENT, "plans[%d] is NULL", k);
+    const size_t np_ = (size_t)npts, tot = (size_t)nplans * np_;
+    // host staging: per plan tD, rD, sv
+    std::vector<double> tD(tot), rD(tot), zD((size_t)nplans * nz);
+    std::vector<int> sv(tot), zl((size_t)nplans * nz);
+    for (int k = 0; k < nplans; k++) {
+        const ucf_derived& D = plans[k]->D;
+        for (int i = 0; i < npts; i++) { tD[k * np_ + i] = t[i] / D.Tc; rD[k * np_ + i] = r[i] / D.Lc; }
+        for (int j = 0; j < nz; j++) zD[(size_t)k * nz + j] = z[j] / D.Lc;
+        int rc = ucf_zlay(plans[k], nz, &zD[(size_t)k * nz], &zl[(size_t)k * nz]);
+        if (rc) return rc;
+        rc = ucf_split_vector(plans[k], npts, &tD[k * np_], &sv[k * np_]);
+        if (rc) return rc;
+        rc = check_sv(plans[k], npts, &sv[k * np_]);
+        if (rc) return rc;
+    }
+    dev_buf b_t, b_r, b_s, b_h, b_d;
+    if (b_t.alloc(sizeof(double) * tot) || b_r.alloc(sizeof(double) * tot) || b_s.alloc(sizeof(int) * tot) ||
+        b_h.alloc(sizeof(double) * tot * nz) || b_d.alloc(sizeof(double) * tot * nz))
+        return fail(UCF_ERR_NOMEM, "device allocation failed for %d plans x %d points", nplans, npts);
+    HIP_TRY(hipMemcpy(b_t.p, tD.data(), sizeof(double) * tot, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(b_r.p, rD.data(), sizeof(double) * tot, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(b_s.p, sv.data(), sizeof(int) * tot, hipMemcpyHostToDevice));
+    const int NS = 8;
+    hipStream_t streams[NS];
+    int ns = 0;
+    for (; ns < NS && ns < nplans; ns++)
+        if (hipStreamCreateWithFlags(&streams[ns], hipStreamNonBlocking) != hipSuccess) break;
+    if (ns == 0) return fail(UCF_ERR_HIP, "cannot create a HIP stream");
+    int rc = UCF_OK;
+    for (int k = 0; k < nplans && rc == UCF_OK; k++) {
+        rc = ucf_drawdown_batch_device(plans[k], npts, (const double*)b_t.p + k * np_, (const double*)b_r.p + k * np_,
+                                       (const int*)b_s.p + k * np_, nz, &zD[(size_t)k * nz], &zl[(size_t)k * nz],
+                                       (double*)b_h.p + k * np_ * nz, (double*)b_d.p + k * np_ * nz, nullptr, streams[k % ns]);
+    }
+    for (int i = 0; i < ns; i++) { (void)hipStreamSynchronize(streams[i]); (void)hipStreamDestroy(streams[i]); }
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(h, b_h.p, sizeof(double) * tot * nz, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(dh, b_d.p, sizeof(double) * tot * nz, hipMemcpyDeviceToHost));
+    if (!dimensionless)
+        for (int k = 0; k < nplans; k++) {
+            const double Hc = plans[k]->D.Hc;
+            for (size_t i = 0; i < np_ * nz; i++) { h[k * np_ * nz + i] *= Hc; dh[k * np_ * nz + i] *= Hc; }
+        }
+    return UCF_OK;
+}
+
 // ---- stage hooks
 int ucf_eval_samples(ucf_plan* pl, int n_a, const double* a, double rD, int np, const double* p_re_im,
                      int nz, const double* zD, const int* zLay, double* fp_re_im)

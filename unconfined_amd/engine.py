@@ -172,6 +172,21 @@ class Plan:
         return out
 
 
+def drawdown_multi(plans, t, r, z, dimensionless: bool = False):
+    """the same dimensional observation points under many parameter sets (inversion / fitting):
+    h, dh of shape [nplans, npts, nz]"""
+    lib = _libmod.load()
+    t, r, z = _f64(t), _f64(r), _f64(z)
+    n, nz, npl = len(t), len(z), len(plans)
+    if len(r) != n:
+        raise ValueError("t and r must have equal length")
+    arr = (C.c_void_p * npl)(*[p._h for p in plans])
+    h = np.zeros((npl, n, nz))
+    dh = np.zeros((npl, n, nz))
+    _libmod.check(lib.ucf_drawdown_multi(arr, npl, n, t, r, nz, z, 1 if dimensionless else 0, h, dh))
+    return h, dh
+
+
 def dehoog(M: int, alpha: float, tol: float, t, tee, fp) -> np.ndarray:
     lib = _libmod.load()
     t, tee, fp = _f64(np.atleast_1d(t)), _f64(np.atleast_1d(tee)), _f64(fp)

@@ -26,7 +26,7 @@ EXPORTS = [
     "ucf_plan_gauss_lobatto", "ucf_plan_set_mode", "ucf_plan_set_timing", "ucf_plan_kernel_ms",
     "ucf_logspace", "ucf_linspace", "ucf_zlay", "ucf_split_vector",
     "ucf_drawdown_batch", "ucf_drawdown_batch_device", "ucf_drawdown_grid", "ucf_drawdown_grid_device",
-    "ucf_screen_average",
+    "ucf_drawdown_multi", "ucf_screen_average",
     "ucf_eval_samples", "ucf_pvalues", "ucf_dehoog", "ucf_wynn_epsilon", "ucf_extraptozero", "ucf_bessel_k01",
     "ucf_fp64_fma_peak",
 ]
@@ -84,6 +84,7 @@ def load() -> C.CDLL:
     lib.ucf_drawdown_batch_device.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int, _dp, _ip, vp, vp, vp, vp]
     lib.ucf_drawdown_grid.argtypes = [vp, C.c_int, _dp, _ip, C.c_int, _dp, C.c_int, _dp, _ip, _dp, _dp, C.POINTER(UcfStats)]
     lib.ucf_drawdown_grid_device.argtypes = [vp, C.c_int, vp, vp, C.c_int, vp, C.c_int, _dp, _ip, vp, vp, vp, vp]
+    lib.ucf_drawdown_multi.argtypes = [C.POINTER(vp), C.c_int, C.c_int, _dp, _dp, C.c_int, _dp, C.c_int, _dp, _dp]
     lib.ucf_screen_average.argtypes = [C.c_int, C.c_int, _dp, _dp]
     lib.ucf_eval_samples.argtypes = [vp, C.c_int, _dp, C.c_double, C.c_int, _dp, C.c_int, _dp, _ip, _dp]
     lib.ucf_pvalues.argtypes = [vp, C.c_double, _dp]
