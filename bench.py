@@ -136,10 +136,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the drawdown path has no CPU fallback")
+    # UCF_BENCH_BACKEND=gloo + UCF_BENCH_ONE_DEVICE=1: rehearsal of the N > 1 logic on a one-GPU box (all
+    # ranks on cuda:0, gather staged through the host); the graded runs use RCCL, one rank per GPU
+    backend = os.environ.get("UCF_BENCH_BACKEND", "nccl")
+    if os.environ.get("UCF_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     if args.gpus != world and rank == 0 and world > 1:
         print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
 
@@ -173,11 +181,19 @@ def main():
     d_all = torch.zeros(world * 2, npts * nz, dtype=torch.float64, device=dev) if world > 1 else None
     stream = torch.cuda.current_stream()
 
+    def gather():
+        if backend == "nccl":
+            dist.all_gather_into_tensor(d_all, d_out)
+        else:                                   # rehearsal path only
+            host_all = torch.empty(d_all.shape, dtype=d_all.dtype)
+            dist.all_gather_into_tensor(host_all, d_out.cpu())
+            d_all.copy_(host_all)
+
     def step():
         plan.drawdown_grid_device(nt, d_tD.data_ptr(), d_sv.data_ptr(), nr, d_rD.data_ptr(), zD, zl,
                                   d_out[0].data_ptr(), d_out[1].data_ptr(), stream=stream.cuda_stream)
         if world > 1:
-            dist.all_gather_into_tensor(d_all, d_out)
+            gather()
 
     for _ in range(args.warmup):
         step()
@@ -204,7 +220,7 @@ def main():
                                   d_out[0].data_ptr(), d_out[1].data_ptr(), stream=stream.cuda_stream)
         ev[k][1].record(stream)
         if world > 1:
-            dist.all_gather_into_tensor(d_all, d_out)
+            gather()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
