@@ -33,7 +33,7 @@ extern "C" {
 
 #define UCF_VERSION 100        /* 0.1.0 */
 #define UCF_MAX_MOENCH 16      /* max number of Moench alphas (driver_io.f90:142-151) */
-#define UCF_MAX_NZ 32          /* max depths per point handled by one launch */
+#define UCF_MAX_NZ 32          /* depths per LAUNCH; calls with more depths are walked in chunks by the library */
 #define UCF_MAX_SCHEDULE 100    /* steps of a piecewise-constant pumping schedule (time.f90:81-95) */
 #define UCF_MAX_LAP_M 63       /* 2M+1 <= 128: the wave-cooperative de Hoog holds at most two samples per lane */
 

@@ -350,6 +350,19 @@ def test_edge_cases(engine, oracle, oracle_quad):
         plan.drawdown(np.array([1.0]), np.array([1.0]), np.array([99], np.int32), zD, zl)     # sv beyond the J0 table
     with pytest.raises(UcfError):
         plan.drawdown(np.array([1.0]), np.array([1.0]), np.array([1], np.int32), zD, np.array([1, 2, 7], np.int32))
+    # many depths (contour maps): the API walks them in LDS-sized chunks; every depth equals its own single call
+    zmany = np.linspace(0.02, 0.98, 23); zlm = plan.zlay(zmany)
+    tq = np.array([0.3, 30.0]); rq = np.array([0.2, 0.9, 4.0])
+    hm, dhm = plan.drawdown_grid(tq, np.ones(2, np.int32), rq, zmany, zlm)
+    assert hm.shape == (2, 3, 23) and np.isfinite(hm).all()
+    for iz in (0, 6, 7, 13, 22):
+        h1, d1 = plan.drawdown_grid(tq, np.ones(2, np.int32), rq, zmany[iz:iz + 1], zlm[iz:iz + 1])
+        assert np.array_equal(h1[..., 0], hm[..., iz]) and np.array_equal(d1[..., 0], dhm[..., iz]), iz
+    TTq, RRq = np.meshgrid(tq, rq, indexing="ij")
+    hbq, dbq = plan.drawdown(TTq.ravel(), RRq.ravel(), np.ones(6, np.int32), zmany, zlm)
+    assert np.array_equal(hbq.reshape(2, 3, 23), hm)
+    hoq, doq = oracle.batch(P, TTq.ravel(), RRq.ravel(), np.ones(6, np.int32), zmany, zlm)
+    assert rel_err(hbq, hoq, 1e-6).max() < 1e-7
     # Laplace sample counts around the wave width: 2M+1 = 63 (one per lane), 65 and 127 (two per lane)
     tDm = np.array([0.05, 1.0, 40.0]); rDm = np.array([0.5, 0.5, 0.5]); svm = np.ones(3, np.int32)
     for M in (31, 32, 63):

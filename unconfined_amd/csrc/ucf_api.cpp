@@ -194,12 +194,26 @@ void gauss_lobatto(int ord, double* xo, double* wo)
     }
 }
 
-int fill_call_params(const ucf_plan* plan, int nz, const double* zD, const int* zLay, ucf_dev_params& dp)
+// depths per launch: as many as keep the wave's LDS footprint <= 40 KB (>= 4 workgroups per CU), at most UCF_MAX_NZ
+int z_chunk(const ucf_plan* plan)
+{
+    const int R = plan->P.R, nacc = plan->P.nacc;
+    const size_t scr = (size_t)(2 * nacc > R ? 2 * nacc : R) * 16 * 16;
+    int n = (int)(((size_t)40 * 1024 - scr) / ((size_t)(R + 1) * UCF_WAVE * 16));
+    if (n < 1) n = 1;
+    if (n > UCF_MAX_NZ) n = UCF_MAX_NZ;
+    return n;
+}
+
+int fill_call_params(const ucf_plan* plan, int nz, const double* zD, const int* zLay, ucf_dev_params& dp,
+                     int nz_out = 0, int z_off = 0)
 {
     if (nz < 1 || nz > UCF_MAX_NZ) return fail(UCF_ERR_BAD_ARGUMENT, "nz=%d out of range 1..%d", nz, UCF_MAX_NZ);
     if (!zD || !zLay) return fail(UCF_ERR_BAD_ARGUMENT, "zD / zLay must not be NULL");
     dp = plan->dev;
     dp.nz = nz;
+    dp.nz_out = nz_out > 0 ? nz_out : nz;
+    dp.z_off = z_off;
     for (int i = 0; i < nz; i++) {
         if (zLay[i] < 1 || zLay[i] > 3) return fail(UCF_ERR_BAD_ARGUMENT, "zLay[%d]=%d not in 1..3", i, zLay[i]);
         dp.zD[i] = zD[i];
@@ -569,17 +583,42 @@ int launch_points_any(ucf_plan* pl, const ucf_dev_params& dp, int npts, int per_
 
 }  // namespace
 
+namespace {
+int grid_device_chunk(ucf_plan* pl, int nt, const double* d_tD, const int* d_sv, int nr, const double* d_rD,
+                      int nz, const double* zD, const int* zLay, int nz_out, int z_off, double* d_h, double* d_dh,
+                      ucf_stats* d_stats, void* stream);
+int batch_device_chunk(ucf_plan* pl, int npts, const double* d_tD, const double* d_rD, const int* d_sv,
+                       int nz, const double* zD, const int* zLay, int nz_out, int z_off, double* d_h, double* d_dh,
+                       ucf_stats* d_stats, void* stream);
+}
+
 int ucf_drawdown_grid_device(ucf_plan* pl, int nt, const double* d_tD, const int* d_sv, int nr, const double* d_rD,
                              int nz, const double* zD, const int* zLay, double* d_h, double* d_dh,
                              ucf_stats* d_stats, void* stream)
 {
     if (!pl) return fail(UCF_ERR_BAD_ARGUMENT, "NULL plan");
     if (nt < 0 || nr < 0) return fail(UCF_ERR_BAD_ARGUMENT, "negative grid size");
+    if (nz < 1) return fail(UCF_ERR_BAD_ARGUMENT, "nz < 1");
     if (nt == 0 || nr == 0) return UCF_OK;
     if ((long long)nt * nr > 0x7fffffffLL) return fail(UCF_ERR_BAD_ARGUMENT, "grid larger than 2^31-1 points: split it");
-    if (!d_tD || !d_rD || !d_sv || !d_h || !d_dh) return fail(UCF_ERR_BAD_ARGUMENT, "NULL device array");
+    if (!d_tD || !d_rD || !d_sv || !d_h || !d_dh || !zD || !zLay) return fail(UCF_ERR_BAD_ARGUMENT, "NULL array");
+    // depths in chunks that fit the wave's LDS budget; each chunk is its own launch sequence on the stream
+    const int zc = z_chunk(pl);
+    for (int z0 = 0; z0 < nz; z0 += zc) {
+        const int n = (nz - z0 < zc) ? nz - z0 : zc;
+        int rc = grid_device_chunk(pl, nt, d_tD, d_sv, nr, d_rD, n, zD + z0, zLay + z0, nz, z0, d_h, d_dh, d_stats, stream);
+        if (rc) return rc;
+    }
+    return UCF_OK;
+}
+
+namespace {
+int grid_device_chunk(ucf_plan* pl, int nt, const double* d_tD, const int* d_sv, int nr, const double* d_rD,
+                      int nz, const double* zD, const int* zLay, int nz_out, int z_off, double* d_h, double* d_dh,
+                      ucf_stats* d_stats, void* stream)
+{
     ucf_dev_params dp;
-    int rc = fill_call_params(pl, nz, zD, zLay, dp);
+    int rc = fill_call_params(pl, nz, zD, zLay, dp, nz_out, z_off);
     if (rc) return rc;
     const int* j0s = pl->P.j0s;
     const int svmin = j0s[0] < j0s[1] ? j0s[0] : j0s[1];
@@ -628,6 +667,7 @@ int ucf_drawdown_grid_device(ucf_plan* pl, int nt, const double* d_tD, const int
     }
     return launch_points_any(pl, dp, nt * nr, 0, nr, nsv, svmin, d_tD, d_rD, d_sv, d_h, d_dh, d_stats, stream);
 }
+}  // namespace
 
 int ucf_drawdown_batch_device(ucf_plan* pl, int npts, const double* d_tD, const double* d_rD, const int* d_sv,
                               int nz, const double* zD, const int* zLay, double* d_h, double* d_dh,
@@ -635,10 +675,25 @@ int ucf_drawdown_batch_device(ucf_plan* pl, int npts, const double* d_tD, const 
 {
     if (!pl) return fail(UCF_ERR_BAD_ARGUMENT, "NULL plan");
     if (npts < 0) return fail(UCF_ERR_BAD_ARGUMENT, "npts < 0");
+    if (nz < 1) return fail(UCF_ERR_BAD_ARGUMENT, "nz < 1");
     if (npts == 0) return UCF_OK;
-    if (!d_tD || !d_rD || !d_sv || !d_h || !d_dh) return fail(UCF_ERR_BAD_ARGUMENT, "NULL device array");
+    if (!d_tD || !d_rD || !d_sv || !d_h || !d_dh || !zD || !zLay) return fail(UCF_ERR_BAD_ARGUMENT, "NULL array");
+    const int zc = z_chunk(pl);
+    for (int z0 = 0; z0 < nz; z0 += zc) {
+        const int n = (nz - z0 < zc) ? nz - z0 : zc;
+        int rc = batch_device_chunk(pl, npts, d_tD, d_rD, d_sv, n, zD + z0, zLay + z0, nz, z0, d_h, d_dh, d_stats, stream);
+        if (rc) return rc;
+    }
+    return UCF_OK;
+}
+
+namespace {
+int batch_device_chunk(ucf_plan* pl, int npts, const double* d_tD, const double* d_rD, const int* d_sv,
+                       int nz, const double* zD, const int* zLay, int nz_out, int z_off, double* d_h, double* d_dh,
+                       ucf_stats* d_stats, void* stream)
+{
     ucf_dev_params dp;
-    int rc = fill_call_params(pl, nz, zD, zLay, dp);
+    int rc = fill_call_params(pl, nz, zD, zLay, dp, nz_out, z_off);
     if (rc) return rc;
     // arbitrary points: one table row per point, in chunks that keep the workspace <= 256 MiB
     const size_t row_bytes = (size_t)pl->D.nabs * 2 * sizeof(double);
@@ -651,12 +706,13 @@ int ucf_drawdown_batch_device(ucf_plan* pl, int npts, const double* d_tD, const 
         const int n = (npts - base < chunk) ? npts - base : chunk;
         rc = ucf_faithful::launch_abscissae(dp, n, 1, 1, 0, d_rD + base, d_sv + base, pl->d_work, stream);
         if (rc) return fail(rc, "abscissa kernel launch failed");
-        rc = launch_points_any(pl, dp, n, 1, 1, 1, 0, d_tD + base, d_rD + base, d_sv + base, d_h + (size_t)base * nz,
-                               d_dh + (size_t)base * nz, d_stats, stream);
+        rc = launch_points_any(pl, dp, n, 1, 1, 1, 0, d_tD + base, d_rD + base, d_sv + base, d_h + (size_t)base * nz_out,
+                               d_dh + (size_t)base * nz_out, d_stats, stream);
         if (rc) return rc;
     }
     return UCF_OK;
 }
+}  // namespace
 
 namespace {
 int check_sv(const ucf_plan* pl, int n, const int* sv)
@@ -734,7 +790,7 @@ int ucf_drawdown_multi(ucf_plan* const* plans, int nplans, int npts, const doubl
                        int nz, const double* z, int dimensionless, double* h, double* dh)
 {
     if (!plans || nplans < 1) return fail(UCF_ERR_BAD_ARGUMENT, "no plans");
-    if (npts < 0 || nz < 1 || nz > UCF_MAX_NZ) return fail(UCF_ERR_BAD_ARGUMENT, "bad sizes");
+    if (npts < 0 || nz < 1) return fail(UCF_ERR_BAD_ARGUMENT, "bad sizes");
     if (npts == 0) return UCF_OK;
     if (!t || !r || !z || !h || !dh) return fail(UCF_ERR_BAD_ARGUMENT, "NULL array");
     for (int k = 0; k < nplans; k++) if (!plans[k]) return fail(UCF_ERR_BAD_ARGUMENT, "plans[%d] is NULL", k);

@@ -904,8 +904,8 @@ point_kernel(const ucf_dev_params P, int npts, int per_point, int nr, int nsv, i
                 const double hval = dehoog_wave(tl, P.M, P.alpha, P.logtol, tD, tee, lane, st);  // :219-223
                 const double dval = dehoog_wave(cmul(tl, p), P.M, P.alpha, P.logtol, tD, tee, lane, st) * tD;   // :225-230
                 if (lane == 0) {
-                    hout[(size_t)pt * nz + z] = hval;
-                    dhout[(size_t)pt * nz + z] = dval;
+                    hout[(size_t)pt * P.nz_out + P.z_off + z] = hval;
+                    dhout[(size_t)pt * P.nz_out + P.z_off + z] = dval;
                 }
             }
         }
@@ -957,8 +957,8 @@ dehoog_points_kernel(const ucf_dev_params P, long long npc, int flat, int per_po
                 dval = dehoog_wave2(tp, P.M, P.alpha, P.logtol, tD, tee, lane, st) * tD;
             }
             if (lane == 0) {
-                hout[obase * nz + z] = hval;
-                dhout[obase * nz + z] = dval;
+                hout[obase * P.nz_out + P.z_off + z] = hval;
+                dhout[obase * P.nz_out + P.z_off + z] = dval;
             }
         }
     }

@@ -14,6 +14,7 @@ struct ucf_dev_params {
     int model, MNtype, order, timeType, MoenchM;
     int M, np, k, N, R, nacc, ngl, nz;
     int nj0z, _pad;
+    int nz_out, z_off;     // depths of the whole call / offset of this launch's chunk: out index = pt*nz_out + z_off + z
     double timePar[2];
     double kappa, alphaD, beta;
     double lD, dD, bD, dD1, lD1;              // dD1 = 1-dD, lD1 = 1-lD (laplace_hankel_solutions.f90:157-158)
