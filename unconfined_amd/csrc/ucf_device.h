@@ -894,10 +894,8 @@ point_kernel(const ucf_dev_params P, int npts, int per_point, int nr, int nsv, i
             }
             const cplx tl = cadd(finint, infint);                                               // :216
             if (LAYOUT == 1) {
-                if (live) {
-                    const size_t lp = (size_t)it * nrc + (ir - ir0);
-                    totlap[(lp * nz + z) * P.np + mlap] = make_double2(tl.re, tl.im);
-                }
+                // [radius of the chunk][z][m][time]: the 64 lanes (consecutive times) store 1 KB contiguously
+                if (live) totlap[(((size_t)(ir - ir0) * nz + z) * P.np + mlap) * nt + it] = make_double2(tl.re, tl.im);
             } else if (LAYOUT == 2) {
                 if (live) totlap[((size_t)pidx * nz + z) * P.np + mlap] = make_double2(tl.re, tl.im);
             } else {
@@ -908,6 +906,67 @@ point_kernel(const ucf_dev_params P, int npts, int per_point, int nr, int nsv, i
                     dhout[(size_t)pt * P.nz_out + P.z_off + z] = dval;
                 }
             }
+        }
+    }
+}
+
+// second half of LAYOUT 1: the transform arrives as [radius][z][m][time] (written coalesced by 64 consecutive
+// times); a wave takes a tile of UCF_DH_TILE consecutive times of one radius, transposes it through LDS
+// ([m][tile], rows padded to dodge bank conflicts) and inverts one time after the other with lane = m
+// (driver.f90:217-230).
+#define UCF_DH_TILE 16
+__global__ void __launch_bounds__(UCF_WAVE)
+dehoog_tiles_kernel(const ucf_dev_params P, int nt, int nr, int ir0, int nrc, const double* __restrict__ tDv,
+                    const double2* __restrict__ totlap, double* __restrict__ hout, double* __restrict__ dhout,
+                    ucf_stats* st)
+{
+    extern __shared__ lds_c lds[];            // [np][UCF_DH_TILE + 1]
+    const int lane = threadIdx.x;
+    const int nz = P.nz, np = P.np;
+    const int ntile = (nt + UCF_DH_TILE - 1) / UCF_DH_TILE;
+    const long long nwork = (long long)nrc * ntile;
+    const int pitch = UCF_DH_TILE + 1;
+    for (long long w = blockIdx.x; w < nwork; w += gridDim.x) {
+        const int irl = (int)(w / ntile), it0 = (int)(w % ntile) * UCF_DH_TILE;
+        const int ncur = (nt - it0 < UCF_DH_TILE) ? nt - it0 : UCF_DH_TILE;
+        for (int z = 0; z < nz; z++) {
+            const double2* src = totlap + ((size_t)irl * nz + z) * np * nt;
+            for (int e = lane; e < np * UCF_DH_TILE; e += UCF_WAVE) {
+                const int m = e / UCF_DH_TILE, tt = e % UCF_DH_TILE;
+                if (tt < ncur) lds[m * pitch + tt] = src[(size_t)m * nt + it0 + tt];
+            }
+            __syncthreads();
+            for (int tt = 0; tt < ncur; tt++) {
+                const int it = it0 + tt;
+                const double tD = tDv[it];
+                const double tee = 2.0 * tD;
+                const double sigma = P.alpha - P.logtol / (2.0 * tee);
+                double hval, dval;
+                if (np <= UCF_WAVE) {
+                    cplx tl = cmake(0.0, 0.0);
+                    if (lane < np) { const lds_c v = lds[lane * pitch + tt]; tl = cmake(v.x, v.y); }
+                    const cplx p = cmake(sigma, UCF_PI * lane / tee);
+                    hval = dehoog_wave(tl, P.M, P.alpha, P.logtol, tD, tee, lane, st);
+                    dval = dehoog_wave(cmul(tl, p), P.M, P.alpha, P.logtol, tD, tee, lane, st) * tD;
+                } else {
+                    cplx tl[2], tp[2];
+#pragma unroll
+                    for (int g = 0; g < 2; g++) {
+                        const int i = lane + 64 * g;
+                        tl[g] = cmake(0.0, 0.0);
+                        if (i < np) { const lds_c v = lds[i * pitch + tt]; tl[g] = cmake(v.x, v.y); }
+                        tp[g] = cmul(tl[g], cmake(sigma, UCF_PI * i / tee));
+                    }
+                    hval = dehoog_wave2(tl, P.M, P.alpha, P.logtol, tD, tee, lane, st);
+                    dval = dehoog_wave2(tp, P.M, P.alpha, P.logtol, tD, tee, lane, st) * tD;
+                }
+                if (lane == 0) {
+                    const size_t o = ((size_t)it * nr + ir0 + irl) * P.nz_out + P.z_off + z;
+                    hout[o] = hval;
+                    dhout[o] = dval;
+                }
+            }
+            __syncthreads();
         }
     }
 }
@@ -1187,9 +1246,10 @@ int launch_grid_transposed(const ucf_dev_params& dp, int nt, int nr, int ir0, in
 #undef UCF_LAUNCH
     if (ev1) (void)hipEventRecord((hipEvent_t)ev1, s);
     if (hipGetLastError() != hipSuccess) return UCF_ERR_HIP;
-    const long long npc = (long long)nt * nrc;
-    hipLaunchKernelGGL(dehoog_points_kernel, dim3((unsigned)(npc > 0x7fffffffLL ? 0x7fffffff : npc)), block, 0, s, dp, npc, 0, 0,
-                       nr, ir0, nrc, d_tD, (const double2*)d_totlap, d_h, d_dh, d_stats);
+    const long long ntl = (long long)nrc * ((nt + UCF_DH_TILE - 1) / UCF_DH_TILE);
+    const size_t dlds = (size_t)dp.np * (UCF_DH_TILE + 1) * sizeof(lds_c);
+    hipLaunchKernelGGL(dehoog_tiles_kernel, dim3((unsigned)(ntl > 0x7fffffffLL ? 0x7fffffff : ntl)), block, dlds, s, dp, nt, nr, ir0,
+                       nrc, d_tD, (const double2*)d_totlap, d_h, d_dh, d_stats);
     return hipGetLastError() == hipSuccess ? UCF_OK : UCF_ERR_HIP;
 }
 
