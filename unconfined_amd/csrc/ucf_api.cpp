@@ -391,6 +391,8 @@ void ucf_plan_destroy(ucf_plan* pl)
     if (pl->d_work) (void)hipFree(pl->d_work);
     if (pl->d_totlap) (void)hipFree(pl->d_totlap);
     if (pl->d_glscr) (void)hipFree(pl->d_glscr);
+    if (pl->d_state) (void)hipFree(pl->d_state);
+    if (pl->d_ndone) (void)hipFree(pl->d_ndone);
     if (pl->ev0) (void)hipEventDestroy((hipEvent_t)pl->ev0);
     if (pl->ev1) (void)hipEventDestroy((hipEvent_t)pl->ev1);
     std::free(pl->h_j0z); std::free(pl->h_ts_x); std::free(pl->h_ts_w); std::free(pl->h_gl_x); std::free(pl->h_gl_w);
@@ -554,30 +556,84 @@ int ensure_glscr(ucf_plan* pl, int nz)
     return UCF_OK;
 }
 
+// state of `items` work items between integrate_kernel and point_kernel (fast flavour, Hantush-based models)
+size_t state_item_bytes(const ucf_plan* pl, const ucf_dev_params& dp)
+{
+    return (pl->mode == 1) ? ucf_fast::state_bytes_per_item(dp) : 0;   // the faithful flavour integrates in point_kernel
+}
+int ensure_state(ucf_plan* pl, const ucf_dev_params& dp, size_t items)
+{
+    const size_t need = state_item_bytes(pl, dp) * items;
+    if (need == 0) return UCF_OK;
+    if (pl->state_bytes < need) {
+        if (pl->d_state) { (void)hipDeviceSynchronize(); (void)hipFree(pl->d_state); pl->d_state = nullptr; pl->state_bytes = 0; }
+        if (hipMalloc((void**)&pl->d_state, need) != hipSuccess) return fail(UCF_ERR_NOMEM, "hipMalloc of %zu integration-state bytes failed", need);
+        pl->state_bytes = need;
+    }
+    if (pl->ndone_items < items) {
+        if (pl->d_ndone) { (void)hipDeviceSynchronize(); (void)hipFree(pl->d_ndone); pl->d_ndone = nullptr; pl->ndone_items = 0; }
+        if (hipMalloc((void**)&pl->d_ndone, items * sizeof(int)) != hipSuccess) return fail(UCF_ERR_NOMEM, "hipMalloc of %zu counters failed", items);
+        pl->ndone_items = items;
+    }
+    return UCF_OK;
+}
+// work items per launch such that their state stays within UCF_STATE_BYTES (default 8 GiB of the 288 GB)
+size_t state_budget()
+{
+    static const size_t b = [] { const char* e = std::getenv("UCF_STATE_BYTES"); long long v = e ? std::atoll(e) : 0; return v > 0 ? (size_t)v : ((size_t)8 << 30); }();
+    return b;
+}
+
 int launch_points_any(ucf_plan* pl, const ucf_dev_params& dp, int npts, int per_point, int nr, int nsv, int svmin,
                       const double* d_tD, const double* d_rD, const int* d_sv, double* d_h, double* d_dh,
                       ucf_stats* d_stats, void* stream)
 {
     int rc = ensure_glscr(pl, dp.nz);
     if (rc) return rc;
-    if (pl->D.np > UCF_WAVE) {
-        // more Laplace samples than lanes: (point, 64-sample chunk) work items + separate inversion kernel
-        const size_t need = (size_t)npts * dp.nz * pl->D.np * 2 * sizeof(double);
+    const bool chunked = pl->D.np > UCF_WAVE;     // more Laplace samples than lanes: (point, 64-sample chunk) work items
+    const int items_per_pt = chunked ? (pl->D.np + UCF_WAVE - 1) / UCF_WAVE : 1;
+    // points per launch: bounded by the integration-state budget; a grid (per_point = 0) is cut at whole time rows
+    size_t step = (size_t)npts;
+    const size_t per_item = state_item_bytes(pl, dp);
+    if (per_item) {
+        step = state_budget() / (per_item * items_per_pt);
+        if (!per_point) step = (step / nr) * nr;
+        if (step < (size_t)(per_point ? 1 : nr)) step = per_point ? 1 : nr;
+        if (step > (size_t)npts) step = npts;
+        rc = ensure_state(pl, dp, step * items_per_pt);
+        if (rc) return rc;
+    }
+    if (chunked) {
+        const size_t need = step * dp.nz * pl->D.np * 2 * sizeof(double);
         if (pl->totlap_bytes < need) {
             if (pl->d_totlap) { (void)hipDeviceSynchronize(); (void)hipFree(pl->d_totlap); pl->d_totlap = nullptr; pl->totlap_bytes = 0; }
             if (hipMalloc((void**)&pl->d_totlap, need) != hipSuccess) return fail(UCF_ERR_NOMEM, "hipMalloc of %zu transform-workspace bytes failed", need);
             pl->totlap_bytes = need;
         }
-        rc = (pl->mode == 1)
-                 ? ucf_fast::launch_points_chunked(dp, npts, per_point, nr, nsv, svmin, d_tD, d_rD, d_sv, pl->d_work, pl->d_totlap, d_h, d_dh, d_stats, stream, pl->d_glscr)
-                 : ucf_faithful::launch_points_chunked(dp, npts, per_point, nr, nsv, svmin, d_tD, d_rD, d_sv, pl->d_work, pl->d_totlap, d_h, d_dh, d_stats, stream, pl->d_glscr);
-    } else {
-        rc = (pl->mode == 1)
-                 ? ucf_fast::launch_points(dp, npts, per_point, nr, nsv, svmin, d_tD, d_rD, d_sv, pl->d_work, d_h, d_dh, d_stats, stream, pl->d_glscr)
-                 : ucf_faithful::launch_points(dp, npts, per_point, nr, nsv, svmin, d_tD, d_rD, d_sv, pl->d_work, d_h, d_dh, d_stats, stream, pl->d_glscr);
     }
-    if (rc == UCF_ERR_UNSUPPORTED) return fail(rc, "this model / size combination has no kernel (model %d, LDS limit)", dp.model);
-    if (rc) return fail(rc, "kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+    const size_t nabs = (size_t)pl->D.nabs;
+    for (size_t base = 0; base < (size_t)npts; base += step) {
+        const int n = (int)(((size_t)npts - base < step) ? (size_t)npts - base : step);
+        // per_point: everything is indexed by the point; grid: times (and their split indices) by the row
+        const size_t tb = per_point ? base : base / nr;
+        const double* tD = d_tD + tb;
+        const int* sv = d_sv + tb;
+        const double* rD = per_point ? d_rD + base : d_rD;
+        const double* tab = per_point ? pl->d_work + base * nabs * 2 : pl->d_work;
+        double* h = d_h + base * dp.nz_out;
+        double* dh = d_dh + base * dp.nz_out;
+        if (chunked) {
+            rc = (pl->mode == 1)
+                     ? ucf_fast::launch_points_chunked(dp, n, per_point, nr, nsv, svmin, tD, rD, sv, tab, pl->d_totlap, h, dh, d_stats, stream, pl->d_glscr, pl->d_state, pl->d_ndone)
+                     : ucf_faithful::launch_points_chunked(dp, n, per_point, nr, nsv, svmin, tD, rD, sv, tab, pl->d_totlap, h, dh, d_stats, stream, pl->d_glscr, nullptr, nullptr);
+        } else {
+            rc = (pl->mode == 1)
+                     ? ucf_fast::launch_points(dp, n, per_point, nr, nsv, svmin, tD, rD, sv, tab, h, dh, d_stats, stream, pl->d_glscr, pl->d_state, pl->d_ndone)
+                     : ucf_faithful::launch_points(dp, n, per_point, nr, nsv, svmin, tD, rD, sv, tab, h, dh, d_stats, stream, pl->d_glscr, nullptr, nullptr);
+        }
+        if (rc == UCF_ERR_UNSUPPORTED) return fail(rc, "this model / size combination has no kernel (model %d, LDS limit)", dp.model);
+        if (rc) return fail(rc, "kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+    }
     return UCF_OK;
 }
 
@@ -636,8 +692,12 @@ int grid_device_chunk(ucf_plan* pl, int nt, const double* d_tD, const int* d_sv,
     if (nsv == 1 && fill_time > fill_lap && !pl->force_layout0) {
         const size_t per_radius = (size_t)nt * nz * pl->D.np * 2 * sizeof(double);
         int nrc = (int)(((size_t)1 << 30) / per_radius);           // <= 1 GiB of workspace per chunk of radii
+        const size_t state_per_radius = state_item_bytes(pl, dp) * ntiles * pl->D.np;
+        if (state_per_radius && (size_t)nrc > state_budget() / state_per_radius) nrc = (int)(state_budget() / state_per_radius);
         if (nrc < 1) nrc = 1;
         if (nrc > nr) nrc = nr;
+        rc = ensure_state(pl, dp, (size_t)nrc * ntiles * pl->D.np);
+        if (rc) return rc;
         if (pl->totlap_bytes < per_radius * nrc) {
             if (pl->d_totlap) { (void)hipDeviceSynchronize(); (void)hipFree(pl->d_totlap); pl->d_totlap = nullptr; pl->totlap_bytes = 0; }
             if (hipMalloc((void**)&pl->d_totlap, per_radius * nrc) != hipSuccess)
@@ -653,13 +713,14 @@ int grid_device_chunk(ucf_plan* pl, int nt, const double* d_tD, const int* d_sv,
             if (!pl->ev0) { hipEvent_t a, b; if (hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) { pl->ev0 = a; pl->ev1 = b; } }
             tev0 = pl->ev0; tev1 = pl->ev1;
             pl->ev_valid = (tev0 && tev1);
-            pl->last_kernel = (pl->mode == 1) ? "ucf_fast::point_kernel<FAMILY, 1>" : "ucf_faithful::point_kernel<FAMILY, 1>";
+            pl->last_kernel = (pl->mode == 1) ? (state_item_bytes(pl, dp) ? "ucf_fast::integrate_kernel<FAMILY, 1>" : "ucf_fast::point_kernel<FAMILY, 1>")
+                                              : "ucf_faithful::point_kernel<FAMILY, 1>";
         }
         for (int ir0 = 0; ir0 < nr; ir0 += nrc) {
             const int n = (nr - ir0 < nrc) ? nr - ir0 : nrc;
             rc = (pl->mode == 1)
-                     ? ucf_fast::launch_grid_transposed(dp, nt, nr, ir0, n, svmin, d_tD, d_rD, pl->d_work, pl->d_totlap, d_h, d_dh, d_stats, stream, tev0, tev1, pl->d_glscr)
-                     : ucf_faithful::launch_grid_transposed(dp, nt, nr, ir0, n, svmin, d_tD, d_rD, pl->d_work, pl->d_totlap, d_h, d_dh, d_stats, stream, tev0, tev1, pl->d_glscr);
+                     ? ucf_fast::launch_grid_transposed(dp, nt, nr, ir0, n, svmin, d_tD, d_rD, pl->d_work, pl->d_totlap, d_h, d_dh, d_stats, stream, tev0, tev1, pl->d_glscr, pl->d_state, pl->d_ndone)
+                     : ucf_faithful::launch_grid_transposed(dp, nt, nr, ir0, n, svmin, d_tD, d_rD, pl->d_work, pl->d_totlap, d_h, d_dh, d_stats, stream, tev0, tev1, pl->d_glscr, nullptr, nullptr);
             if (rc == UCF_ERR_UNSUPPORTED) return fail(rc, "this model / size combination has no kernel (model %d, LDS limit)", dp.model);
             if (rc) return fail(rc, "kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
         }

@@ -739,12 +739,57 @@ abscissa_kernel(const ucf_dev_params P, int nrows, int per_point, int nsv, int s
 //             transform totlap(t, r, z, m) goes to an HBM workspace (16 B per sample point) and
 //             dehoog_points_kernel inverts it with lane = m.  Per-lane arithmetic is identical to LAYOUT 0,
 //             so both give the same bits.
+// decoding of a work-item index into (time, radius, Laplace index), shared by the kernels below
+struct work_item {
+    int it, ir, mlap, pidx;
+    bool live;
+};
+template <int LAYOUT>
+UCF_DEV work_item decode_item(const ucf_dev_params& P, int pt, int lane, int per_point, int nr, int nt, int ir0)
+{
+    work_item W;
+    if (LAYOUT == 0) {
+        W.it = per_point ? pt : pt / nr;
+        W.ir = per_point ? pt : pt % nr;
+        W.mlap = lane;
+        W.live = lane < P.np;
+        W.pidx = pt;
+    } else if (LAYOUT == 2) {
+        // 2M+1 > 64: work item = (point, chunk of 64 Laplace samples); inversion in dehoog_points_kernel
+        const int nchunk = (P.np + UCF_WAVE - 1) / UCF_WAVE;
+        const int q = pt / nchunk;
+        W.it = per_point ? q : q / nr;
+        W.ir = per_point ? q : q % nr;
+        W.mlap = (pt % nchunk) * UCF_WAVE + lane;
+        W.live = W.mlap < P.np;
+        W.pidx = q;
+    } else {
+        // work item = (radius of this chunk, tile of 64 times, Laplace index); m fastest so that
+        // neighbouring waves share the abscissa row and the times
+        const int ntiles = (nt + UCF_WAVE - 1) / UCF_WAVE;
+        W.mlap = pt % P.np;
+        const int tile = (pt / P.np) % ntiles;
+        W.ir = ir0 + pt / (P.np * ntiles);
+        W.it = tile * UCF_WAVE + lane;
+        W.live = W.it < nt;
+        if (!W.live) W.it = nt - 1;
+        W.pidx = pt;
+    }
+    return W;
+}
+
+// State handed from integrate_kernel to point_kernel (fast flavour): per work item
+// [(R + 1 + nacc) * nz][64] complex = level sums | area of the interval in progress | finished areas,
+// plus the number of abscissae already integrated.
+UCF_DEV size_t state_slots(const ucf_dev_params& P) { return (size_t)(P.R + 1 + P.nacc) * P.nz; }
+
 template <int FAMILY, int LAYOUT>
 __global__ void __launch_bounds__(UCF_WAVE, 2)
 point_kernel(const ucf_dev_params P, int npts, int per_point, int nr, int nsv, int svmin,
              const double* __restrict__ tDv, const double* __restrict__ rDv, const int* __restrict__ svv,
              const double2* __restrict__ tab, double* __restrict__ hout, double* __restrict__ dhout, ucf_stats* st,
-             int nt, int ir0, int nrc, double2* __restrict__ totlap, double2* __restrict__ glscr)
+             int nt, int ir0, int nrc, double2* __restrict__ totlap, double2* __restrict__ glscr,
+             double2* __restrict__ state, const int* __restrict__ ndone)
 {
     extern __shared__ lds_c lds[];
     const int lane = threadIdx.x;
@@ -755,8 +800,10 @@ point_kernel(const ucf_dev_params P, int npts, int per_point, int nr, int nsv, i
     lds_c* scr = accCur + (size_t)nz * UCF_WAVE;            // [max(2 nacc, R)] quarter-wave slots: Wynn columns / Neville
     lds_c* accGL = scr + (size_t)(2 * nacc > R ? 2 * nacc : R) * UCF_PART;   // [nacc][nz] finished areas (if kept in LDS)
     // finished interval areas: in LDS while that does not cost occupancy (nz = 1), else in an L2-resident
-    // global scratch slot of this (then persistent, grid-strided) workgroup: [nacc][nz][64] complex
-    const bool areas_lds = (glscr == nullptr);
+    // global scratch slot of this (then persistent, grid-strided) workgroup: [nacc][nz][64] complex;
+    // when resuming after integrate_kernel they stay where that kernel put them (the item's state)
+    const bool resume = (state != nullptr);
+    const bool areas_lds = (glscr == nullptr) && !resume;
     lds_c* fdbuf = accGL + (areas_lds ? (size_t)nacc * nz * UCF_WAVE : 0);
     double2* __restrict__ areas = areas_lds ? nullptr : glscr + (size_t)blockIdx.x * nacc * nz * UCF_WAVE;
 
@@ -764,47 +811,28 @@ point_kernel(const ucf_dev_params P, int npts, int per_point, int nr, int nsv, i
     for (int z = 0; z < nz; z++) need_lay1 |= (P.zLay[z] == 1);
 
     for (int pt = blockIdx.x; pt < npts; pt += gridDim.x) {
-        int it, ir, mlap;
-        bool live;
-        if (LAYOUT == 0) {
-            it = per_point ? pt : pt / nr;
-            ir = per_point ? pt : pt % nr;
-            mlap = lane;
-            live = lane < P.np;
-        } else if (LAYOUT == 2) {
-            // 2M+1 > 64: work item = (point, chunk of 64 Laplace samples); inversion in dehoog_points_kernel
-            const int nchunk = (P.np + UCF_WAVE - 1) / UCF_WAVE;
-            const int q = pt / nchunk;
-            it = per_point ? q : q / nr;
-            ir = per_point ? q : q % nr;
-            mlap = (pt % nchunk) * UCF_WAVE + lane;
-            live = mlap < P.np;
-        } else {
-            // work item = (radius of this chunk, tile of 64 times, Laplace index); m fastest so that
-            // neighbouring waves share the abscissa row and the times
-            const int ntiles = (nt + UCF_WAVE - 1) / UCF_WAVE;
-            mlap = pt % P.np;
-            const int tile = (pt / P.np) % ntiles;
-            ir = ir0 + pt / (P.np * ntiles);
-            it = tile * UCF_WAVE + lane;
-            live = it < nt;
-            if (!live) it = nt - 1;
-        }
+        const work_item W = decode_item<LAYOUT>(P, pt, lane, per_point, nr, nt, ir0);
+        const int it = W.it, ir = W.ir, mlap = W.mlap, pidx = W.pidx;
+        const bool live = W.live;
         const double tD = tDv[it], rD = rDv[ir];
         const int sv = (LAYOUT == 1) ? svmin : svv[it];
-        const int pidx = (LAYOUT == 2) ? pt / ((P.np + UCF_WAVE - 1) / UCF_WAVE) : pt;     // point index of this work item
         const double2* __restrict__ row = tab + (size_t)(per_point ? pidx : (ir * nsv + (sv - svmin))) * nabs;
         const double tee = 2.0 * tD;                                                            // driver.f90:106,217
         const double sigma = P.alpha - P.logtol / (2.0 * tee);                                  // invlap.f90:165
         const cplx p = cmake(sigma, UCF_PI * mlap / tee);                                       // invlap.f90:168
         const cplx lt = lap_time(P, p);
         const double arg = P.j0z[sv - 1] / rD;                                                  // driver.f90:120
-#if UCF_FAST
-        const lane_consts LC = make_lane_consts(P, p, lt);
-#endif
         const cplx lane_aux = (FAMILY == 5) ? hstorage_A0(P, p) : cmake(0.0, 0.0);
 
-        for (int s = 0; s < (R + 1) * nz; s++) lds_st(lds, s, lane, cmake(0.0, 0.0));
+        int n = 0;
+        if (resume) {
+            double2* __restrict__ sti = state + (size_t)pt * state_slots(P) * UCF_WAVE;
+            for (int s = 0; s < (R + 1) * nz; s++) lds[s * UCF_WAVE + lane] = sti[(size_t)s * UCF_WAVE + lane];
+            areas = sti + (size_t)(R + 1) * nz * UCF_WAVE;
+            n = ndone[pt];
+        } else {
+            for (int s = 0; s < (R + 1) * nz; s++) lds_st(lds, s, lane, cmake(0.0, 0.0));
+        }
 
         // one pass over all abscissae: n < N tanh-sinh on [0,arg] feeding every Richardson level
         // (driver.f90:129-157); n >= N Gauss-Lobatto between successive J0 zeros (:187-203)
@@ -837,20 +865,6 @@ point_kernel(const ucf_dev_params P, int npts, int per_point, int nr, int nsv, i
                 lds_st(accCur, z, lane, acc);
             }
         };
-        int n = 0;
-#if UCF_FAST
-        // abscissae increase monotonically (tanh-sinh on [0,arg], then the J0 intervals), so does Re(eta):
-        // the fast evaluation is valid for a leading run of abscissae; the generic evaluator finishes the rest
-        if (FAMILY == 1 || FAMILY == 2 || FAMILY == 4) {
-            for (; n < nabs; n++) {
-                const double2 aa = row[n];
-                fast_common F;
-                const bool ok = fast_prepare<FAMILY>(P, LC, aa.x, need_lay1, F);
-                if (!__all(ok)) break;
-                for (int z = 0; z < nz; z++) accumulate(n, aa.y, z, fast_sample_z<FAMILY>(P, F, z));
-            }
-        }
-#endif
         for (; n < nabs; n++) {
             const double2 aa = row[n];
             sample_common S;
@@ -909,6 +923,91 @@ point_kernel(const ucf_dev_params P, int npts, int per_point, int nr, int nsv, i
         }
     }
 }
+
+#if UCF_FAST
+// ------------------------------------------------------------------ the integration kernel (fast flavour)
+// The abscissa loop of point_kernel on its own (driver.f90:129-157,187-203 with the fast evaluators of
+// ucf_fastpath.h): same work items, same lanes, same accumulation order.  It owns nothing but the loop, so
+// that it needs half the registers and a quarter of the LDS of point_kernel and runs at twice the
+// occupancy: a wave can issue one instruction per 4-cycle slot at best and a dependent fp64 result takes
+// ~2.2 slots, so the VALU is only kept busy by waves, not by one wave's instruction stream.
+// The level sums, the running interval area and the finished interval areas go to the item's state
+// (HBM, written once, coalesced 1 KB per slot); point_kernel resumes from there: remaining abscissae
+// with the generic evaluator (the overflow regime the fast one leaves alone), Richardson, Wynn, de Hoog.
+#ifndef UCF_INTEGRATE_WAVES
+#define UCF_INTEGRATE_WAVES 4
+#endif
+template <int FAMILY, int LAYOUT>
+__global__ void __launch_bounds__(UCF_WAVE, UCF_INTEGRATE_WAVES)
+integrate_kernel(const ucf_dev_params P, int npts, int per_point, int nr, int nsv, int svmin,
+                 const double* __restrict__ tDv, const double* __restrict__ rDv, const int* __restrict__ svv,
+                 const double2* __restrict__ tab, int nt, int ir0, double2* __restrict__ state, int* __restrict__ ndone)
+{
+    extern __shared__ lds_c lds[];
+    const int lane = threadIdx.x;
+    const int nz = P.nz, R = P.R, nacc = P.nacc, N = P.N, ngl = P.ngl;
+    const int nabs = N + nacc * ngl;
+    lds_c* accTS = lds;                                     // [R][nz]  level sums
+    lds_c* accCur = lds + (size_t)R * nz * UCF_WAVE;        // [nz]     area of the J0 interval being integrated
+    bool need_lay1 = false;
+    for (int z = 0; z < nz; z++) need_lay1 |= (P.zLay[z] == 1);
+
+    for (int pt = blockIdx.x; pt < npts; pt += gridDim.x) {
+        const work_item W = decode_item<LAYOUT>(P, pt, lane, per_point, nr, nt, ir0);
+        const double tD = tDv[W.it], rD = rDv[W.ir];
+        const int sv = (LAYOUT == 1) ? svmin : svv[W.it];
+        const double2* __restrict__ row = tab + (size_t)(per_point ? W.pidx : (W.ir * nsv + (sv - svmin))) * nabs;
+        const double tee = 2.0 * tD;                                                            // driver.f90:106,217
+        const double sigma = P.alpha - P.logtol / (2.0 * tee);                                  // invlap.f90:165
+        const cplx p = cmake(sigma, UCF_PI * W.mlap / tee);                                     // invlap.f90:168
+        const cplx lt = lap_time(P, p);
+        const lane_consts LC = make_lane_consts(P, p, lt);
+        double2* __restrict__ sti = state + (size_t)pt * state_slots(P) * UCF_WAVE;
+        double2* __restrict__ areas = sti + (size_t)(R + 1) * nz * UCF_WAVE;
+        for (int s = 0; s < (R + 1) * nz; s++) lds_st(lds, s, lane, cmake(0.0, 0.0));
+
+        // abscissae increase monotonically (tanh-sinh on [0,arg], then the J0 intervals), so does Re(eta):
+        // the fast evaluation is valid for a leading run of abscissae; point_kernel finishes the rest
+        int n = 0;
+        for (; n < nabs; n++) {
+            const double2 aa = row[n];
+            fast_common F;
+            const bool ok = fast_prepare<FAMILY>(P, LC, aa.x, need_lay1, F);
+            if (!__all(ok)) break;
+            for (int z = 0; z < nz; z++) {
+                // val = a*J0(a rD) * f(a,p,z) * lapTime(p)                                      (lhs.f90:118)
+                const cplx val = cmul(rscale(aa.y, fast_sample_z<FAMILY>(P, F, z)), lt);
+                if (n < N) {
+                    // abscissa n+1 belongs to level j when 2^(R-j) divides it                  (driver.f90:150)
+                    const int n1 = n + 1;
+                    int tz = __builtin_ctz(n1);
+                    if (tz > R - 1) tz = R - 1;
+                    for (int sh = 0; sh <= tz; sh++) {
+                        const int j = R - sh;
+                        const double w = P.ts_w[(size_t)(j - 1) * N + ((n1 >> sh) - 1)];
+                        const int slot = (j - 1) * nz + z;
+                        lds_st(accTS, slot, lane, cadd(lds_ld(accTS, slot, lane), rscale(w, val)));
+                    }
+                } else {
+                    const int g = n - N;
+                    const int jj = g / ngl, m = g - jj * ngl;
+                    cplx acc = cadd(lds_ld(accCur, z, lane), cscale(val, P.gl_w[m]));           // :201-202
+                    if (m == ngl - 1) {
+                        const double lob = P.j0z[sv + jj - 1] / rD;
+                        const double hib = P.j0z[sv + jj] / rD;
+                        acc = rscale((hib - lob) / 2.0, acc);
+                        areas[(size_t)(jj * nz + z) * UCF_WAVE + lane] = make_double2(acc.re, acc.im);
+                        acc = cmake(0.0, 0.0);
+                    }
+                    lds_st(accCur, z, lane, acc);
+                }
+            }
+        }
+        for (int s = 0; s < (R + 1) * nz; s++) sti[(size_t)s * UCF_WAVE + lane] = lds[s * UCF_WAVE + lane];
+        if (lane == 0) ndone[pt] = n;
+    }
+}
+#endif
 
 // second half of LAYOUT 1: the transform arrives as [radius][z][m][time] (written coalesced by 64 consecutive
 // times); a wave takes a tile of UCF_DH_TILE consecutive times of one radius, transposes it through LDS
@@ -1158,9 +1257,9 @@ static inline bool areas_in_lds(const ucf_dev_params& dp)
     return with_areas <= 20 * 1024;
 }
 
-static inline size_t point_lds_bytes(const ucf_dev_params& dp)
+static inline size_t point_lds_bytes(const ucf_dev_params& dp, bool resume = false)
 {
-    size_t bytes = ((size_t)(dp.R + 1 + (areas_in_lds(dp) ? dp.nacc : 0)) * dp.nz * UCF_WAVE + (size_t)(2 * dp.nacc > dp.R ? 2 * dp.nacc : dp.R) * UCF_PART) * sizeof(lds_c);
+    size_t bytes = ((size_t)(dp.R + 1 + ((areas_in_lds(dp) && !resume) ? dp.nacc : 0)) * dp.nz * UCF_WAVE + (size_t)(2 * dp.nacc > dp.R ? 2 * dp.nacc : dp.R) * UCF_PART) * sizeof(lds_c);
 #if !UCF_FAST
     if (family_of(dp) == 4) bytes += 2 * (size_t)dp.order * UCF_WAVE * sizeof(lds_c);
 #endif
@@ -1180,60 +1279,71 @@ int launch_abscissae(const ucf_dev_params& dp, int nrows, int per_point, int nsv
 }
 #endif
 
-int launch_points(const ucf_dev_params& dp, int npts, int per_point, int nr, int nsv, int svmin, const double* d_tD,
-                  const double* d_rD, const int* d_sv, const double* d_tab, double* d_h, double* d_dh,
-                  ucf_stats* d_stats, void* stream, double* d_glscr)
+// does this flavour integrate in its own kernel (integrate_kernel -> point_kernel resuming from the state)?
+static inline bool split_integration(const ucf_dev_params& dp)
 {
+#if UCF_FAST
     const int fam = family_of(dp);
-    if (fam < 0) return UCF_ERR_UNSUPPORTED;
-    const size_t lds = point_lds_bytes(dp);
-    if (lds > 160 * 1024) return UCF_ERR_UNSUPPORTED;
-    hipStream_t s = (hipStream_t)stream;
-    const bool al = areas_in_lds(dp);
-    if (al) d_glscr = nullptr;
-    dim3 grid((al || npts < UCF_GRID_SLOTS) ? npts : UCF_GRID_SLOTS), block(UCF_WAVE);
-#define UCF_LAUNCH(F)                                                                                          \
-    do {                                                                                                       \
-        if (lds > 64 * 1024)                                                                                   \
-            (void)hipFuncSetAttribute((const void*)point_kernel<F, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((point_kernel<F, 0>), grid, block, lds, s, dp, npts, per_point, nr, nsv, svmin, d_tD, d_rD, d_sv, \
-                           (const double2*)d_tab, d_h, d_dh, d_stats, 0, 0, 0, (double2*)nullptr, (double2*)d_glscr); \
-    } while (0)
-    switch (fam) {
-    case 0: UCF_LAUNCH(0); break;
-    case 1: UCF_LAUNCH(1); break;
-    case 2: UCF_LAUNCH(2); break;
-    case 3: UCF_LAUNCH(3); break;
-    case 4: UCF_LAUNCH(4); break;
-    case 5: UCF_LAUNCH(5); break;
-    }
-#undef UCF_LAUNCH
-    return hipGetLastError() == hipSuccess ? UCF_OK : UCF_ERR_HIP;
+    return fam == 1 || fam == 2 || fam == 4;
+#else
+    return false;
+#endif
+}
+// bytes of state per work item (0: no state needed)
+size_t state_bytes_per_item(const ucf_dev_params& dp)
+{
+    return split_integration(dp) ? (size_t)(dp.R + 1 + dp.nacc) * dp.nz * UCF_WAVE * sizeof(lds_c) : 0;
 }
 
-// LAYOUT 1 (lane = time): transform kernel over (radius chunk x time tiles x Laplace index), then de Hoog
-int launch_grid_transposed(const ucf_dev_params& dp, int nt, int nr, int ir0, int nrc, int svmin, const double* d_tD,
-                           const double* d_rD, const double* d_tab, double* d_totlap, double* d_h, double* d_dh,
-                           ucf_stats* d_stats, void* stream, void* ev0, void* ev1, double* d_glscr)
+// The transform stage for `nwork` work items of lane layout LAYOUT: [integrate_kernel ->] point_kernel.
+// ev0/ev1 (optional) bracket the dominant kernel: integrate_kernel when the flavour has one, else point_kernel.
+template <int LAYOUT>
+static int launch_transform(const ucf_dev_params& dp, int nwork, int per_point, int nr, int nsv, int svmin, const double* d_tD,
+                            const double* d_rD, const int* d_sv, const double* d_tab, double* d_h, double* d_dh,
+                            ucf_stats* d_stats, int nt, int ir0, int nrc, double* d_totlap, double* d_glscr,
+                            double* d_state, int* d_ndone, void* stream, void* ev0, void* ev1)
 {
     const int fam = family_of(dp);
     if (fam < 0) return UCF_ERR_UNSUPPORTED;
-    const size_t lds = point_lds_bytes(dp);
+    const bool split = split_integration(dp);
+    if (split && (!d_state || !d_ndone)) return UCF_ERR_BAD_ARGUMENT;
+    const size_t lds = point_lds_bytes(dp, split);
     if (lds > 160 * 1024) return UCF_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
-    if (ev0) (void)hipEventRecord((hipEvent_t)ev0, s);
-    const int ntiles = (nt + UCF_WAVE - 1) / UCF_WAVE;
-    const long long nwork = (long long)nrc * ntiles * dp.np;
-    if (nwork > 0x7fffffffLL) return UCF_ERR_BAD_ARGUMENT;
-    const bool al = areas_in_lds(dp);
+    const bool al = areas_in_lds(dp) || split;
     if (al) d_glscr = nullptr;
+    if (!split) { d_state = nullptr; d_ndone = nullptr; }
     dim3 grid((unsigned)((al || nwork < UCF_GRID_SLOTS) ? nwork : UCF_GRID_SLOTS)), block(UCF_WAVE);
+#if UCF_FAST
+    if (split) {
+        const size_t ilds = (size_t)(dp.R + 1) * dp.nz * UCF_WAVE * sizeof(lds_c);
+        if (ev0) (void)hipEventRecord((hipEvent_t)ev0, s);
+#define UCF_LAUNCH_I(F)                                                                                        \
+    do {                                                                                                       \
+        if (ilds > 64 * 1024)                                                                                  \
+            (void)hipFuncSetAttribute((const void*)integrate_kernel<F, LAYOUT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ilds); \
+        hipLaunchKernelGGL((integrate_kernel<F, LAYOUT>), dim3((unsigned)nwork), block, ilds, s, dp, nwork, per_point, nr, nsv, svmin, \
+                           d_tD, d_rD, d_sv, (const double2*)d_tab, nt, ir0, (double2*)d_state, d_ndone);      \
+    } while (0)
+        switch (fam) {
+        case 1: UCF_LAUNCH_I(1); break;
+        case 2: UCF_LAUNCH_I(2); break;
+        case 4: UCF_LAUNCH_I(4); break;
+        }
+#undef UCF_LAUNCH_I
+        if (ev1) (void)hipEventRecord((hipEvent_t)ev1, s);
+        if (hipGetLastError() != hipSuccess) return UCF_ERR_HIP;
+        ev0 = ev1 = nullptr;
+    }
+#endif
+    if (ev0) (void)hipEventRecord((hipEvent_t)ev0, s);
 #define UCF_LAUNCH(F)                                                                                          \
     do {                                                                                                       \
         if (lds > 64 * 1024)                                                                                   \
-            (void)hipFuncSetAttribute((const void*)point_kernel<F, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((point_kernel<F, 1>), grid, block, lds, s, dp, (int)nwork, 0, nr, 1, svmin, d_tD, d_rD,           \
-                           (const int*)nullptr, (const double2*)d_tab, d_h, d_dh, d_stats, nt, ir0, nrc, (double2*)d_totlap, (double2*)d_glscr); \
+            (void)hipFuncSetAttribute((const void*)point_kernel<F, LAYOUT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((point_kernel<F, LAYOUT>), grid, block, lds, s, dp, nwork, per_point, nr, nsv, svmin, d_tD, d_rD, d_sv, \
+                           (const double2*)d_tab, d_h, d_dh, d_stats, nt, ir0, nrc, (double2*)d_totlap, (double2*)d_glscr,          \
+                           (double2*)d_state, (const int*)d_ndone);                                            \
     } while (0)
     switch (fam) {
     case 0: UCF_LAUNCH(0); break;
@@ -1245,10 +1355,34 @@ int launch_grid_transposed(const ucf_dev_params& dp, int nt, int nr, int ir0, in
     }
 #undef UCF_LAUNCH
     if (ev1) (void)hipEventRecord((hipEvent_t)ev1, s);
-    if (hipGetLastError() != hipSuccess) return UCF_ERR_HIP;
+    return hipGetLastError() == hipSuccess ? UCF_OK : UCF_ERR_HIP;
+}
+
+// LAYOUT 0 (lane = Laplace sample, de Hoog in the same wave)
+int launch_points(const ucf_dev_params& dp, int npts, int per_point, int nr, int nsv, int svmin, const double* d_tD,
+                  const double* d_rD, const int* d_sv, const double* d_tab, double* d_h, double* d_dh,
+                  ucf_stats* d_stats, void* stream, double* d_glscr, double* d_state, int* d_ndone)
+{
+    return launch_transform<0>(dp, npts, per_point, nr, nsv, svmin, d_tD, d_rD, d_sv, d_tab, d_h, d_dh, d_stats, 0, 0, 0,
+                               nullptr, d_glscr, d_state, d_ndone, stream, nullptr, nullptr);
+}
+
+// LAYOUT 1 (lane = time): transform kernel(s) over (radius chunk x time tiles x Laplace index), then de Hoog
+int launch_grid_transposed(const ucf_dev_params& dp, int nt, int nr, int ir0, int nrc, int svmin, const double* d_tD,
+                           const double* d_rD, const double* d_tab, double* d_totlap, double* d_h, double* d_dh,
+                           ucf_stats* d_stats, void* stream, void* ev0, void* ev1, double* d_glscr, double* d_state,
+                           int* d_ndone)
+{
+    hipStream_t s = (hipStream_t)stream;
+    const int ntiles = (nt + UCF_WAVE - 1) / UCF_WAVE;
+    const long long nwork = (long long)nrc * ntiles * dp.np;
+    if (nwork > 0x7fffffffLL) return UCF_ERR_BAD_ARGUMENT;
+    int rc = launch_transform<1>(dp, (int)nwork, 0, nr, 1, svmin, d_tD, d_rD, nullptr, d_tab, d_h, d_dh, d_stats, nt, ir0, nrc,
+                                 d_totlap, d_glscr, d_state, d_ndone, stream, ev0, ev1);
+    if (rc) return rc;
     const long long ntl = (long long)nrc * ((nt + UCF_DH_TILE - 1) / UCF_DH_TILE);
     const size_t dlds = (size_t)dp.np * (UCF_DH_TILE + 1) * sizeof(lds_c);
-    hipLaunchKernelGGL(dehoog_tiles_kernel, dim3((unsigned)(ntl > 0x7fffffffLL ? 0x7fffffff : ntl)), block, dlds, s, dp, nt, nr, ir0,
+    hipLaunchKernelGGL(dehoog_tiles_kernel, dim3((unsigned)(ntl > 0x7fffffffLL ? 0x7fffffff : ntl)), dim3(UCF_WAVE), dlds, s, dp, nt, nr, ir0,
                        nrc, d_tD, (const double2*)d_totlap, d_h, d_dh, d_stats);
     return hipGetLastError() == hipSuccess ? UCF_OK : UCF_ERR_HIP;
 }
@@ -1257,37 +1391,16 @@ int launch_grid_transposed(const ucf_dev_params& dp, int nt, int nr, int ir0, in
 // Same addressing as launch_points; d_h/d_dh/d_totlap point at this chunk of points.
 int launch_points_chunked(const ucf_dev_params& dp, int npts, int per_point, int nr, int nsv, int svmin, const double* d_tD,
                           const double* d_rD, const int* d_sv, const double* d_tab, double* d_totlap, double* d_h,
-                          double* d_dh, ucf_stats* d_stats, void* stream, double* d_glscr)
+                          double* d_dh, ucf_stats* d_stats, void* stream, double* d_glscr, double* d_state, int* d_ndone)
 {
-    const int fam = family_of(dp);
-    if (fam < 0) return UCF_ERR_UNSUPPORTED;
-    const size_t lds = point_lds_bytes(dp);
-    if (lds > 160 * 1024) return UCF_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     const int nchunk = (dp.np + UCF_WAVE - 1) / UCF_WAVE;
     const long long nwork = (long long)npts * nchunk;
     if (nwork > 0x7fffffffLL) return UCF_ERR_BAD_ARGUMENT;
-    const bool al = areas_in_lds(dp);
-    if (al) d_glscr = nullptr;
-    dim3 grid((unsigned)((al || nwork < UCF_GRID_SLOTS) ? nwork : UCF_GRID_SLOTS)), block(UCF_WAVE);
-#define UCF_LAUNCH(F)                                                                                          \
-    do {                                                                                                       \
-        if (lds > 64 * 1024)                                                                                   \
-            (void)hipFuncSetAttribute((const void*)point_kernel<F, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((point_kernel<F, 2>), grid, block, lds, s, dp, (int)nwork, per_point, nr, nsv, svmin, d_tD, d_rD, \
-                           d_sv, (const double2*)d_tab, d_h, d_dh, d_stats, 0, 0, 0, (double2*)d_totlap, (double2*)d_glscr); \
-    } while (0)
-    switch (fam) {
-    case 0: UCF_LAUNCH(0); break;
-    case 1: UCF_LAUNCH(1); break;
-    case 2: UCF_LAUNCH(2); break;
-    case 3: UCF_LAUNCH(3); break;
-    case 4: UCF_LAUNCH(4); break;
-    case 5: UCF_LAUNCH(5); break;
-    }
-#undef UCF_LAUNCH
-    if (hipGetLastError() != hipSuccess) return UCF_ERR_HIP;
-    hipLaunchKernelGGL(dehoog_points_kernel, dim3((unsigned)npts), block, 0, s, dp, (long long)npts, 1, per_point, nr, 0, 0, d_tD,
+    int rc = launch_transform<2>(dp, (int)nwork, per_point, nr, nsv, svmin, d_tD, d_rD, d_sv, d_tab, d_h, d_dh, d_stats, 0, 0, 0,
+                                 d_totlap, d_glscr, d_state, d_ndone, stream, nullptr, nullptr);
+    if (rc) return rc;
+    hipLaunchKernelGGL(dehoog_points_kernel, dim3((unsigned)npts), dim3(UCF_WAVE), 0, s, dp, (long long)npts, 1, per_point, nr, 0, 0, d_tD,
                        (const double2*)d_totlap, d_h, d_dh, d_stats);
     return hipGetLastError() == hipSuccess ? UCF_OK : UCF_ERR_HIP;
 }

@@ -28,17 +28,16 @@ UCF_DEV double exp_pos(double x)
     const double k = __builtin_rint(x * 1.4426950408889634074);
     double r = __builtin_fma(-k, 6.93147180369123816490e-01, x);
     r = __builtin_fma(-k, 1.90821492927058770002e-10, r);
-    double q = 1.0 / 6227020800.0;
-    q = __builtin_fma(q, r, 1.0 / 479001600.0);
-    q = __builtin_fma(q, r, 1.0 / 39916800.0);
-    q = __builtin_fma(q, r, 1.0 / 3628800.0);
-    q = __builtin_fma(q, r, 1.0 / 362880.0);
-    q = __builtin_fma(q, r, 1.0 / 40320.0);
-    q = __builtin_fma(q, r, 1.0 / 5040.0);
-    q = __builtin_fma(q, r, 1.0 / 720.0);
-    q = __builtin_fma(q, r, 1.0 / 120.0);
-    q = __builtin_fma(q, r, 1.0 / 24.0);
-    q = __builtin_fma(q, r, 1.0 / 6.0);
+    double q = addk(mulk(r, 1.0 / 6227020800.0), 1.0 / 479001600.0);
+    q = fmak(q, r, 1.0 / 39916800.0);
+    q = fmak(q, r, 1.0 / 3628800.0);
+    q = fmak(q, r, 1.0 / 362880.0);
+    q = fmak(q, r, 1.0 / 40320.0);
+    q = fmak(q, r, 1.0 / 5040.0);
+    q = fmak(q, r, 1.0 / 720.0);
+    q = fmak(q, r, 1.0 / 120.0);
+    q = fmak(q, r, 1.0 / 24.0);
+    q = fmak(q, r, 1.0 / 6.0);
     q = __builtin_fma(q, r, 0.5);
     q = __builtin_fma(q, r, 1.0);
     q = __builtin_fma(q, r, 1.0);
@@ -56,12 +55,11 @@ UCF_DEV fprim prim(double x, double y)
     double s;
     if (ax < 0.35) {
         const double x2 = ax * ax;
-        double pl = 1.0 / 6227020800.0;
-        pl = __builtin_fma(pl, x2, 1.0 / 39916800.0);
-        pl = __builtin_fma(pl, x2, 1.0 / 362880.0);
-        pl = __builtin_fma(pl, x2, 1.0 / 5040.0);
-        pl = __builtin_fma(pl, x2, 1.0 / 120.0);
-        pl = __builtin_fma(pl, x2, 1.0 / 6.0);
+        double pl = addk(mulk(x2, 1.0 / 6227020800.0), 1.0 / 39916800.0);
+        pl = fmak(pl, x2, 1.0 / 362880.0);
+        pl = fmak(pl, x2, 1.0 / 5040.0);
+        pl = fmak(pl, x2, 1.0 / 120.0);
+        pl = fmak(pl, x2, 1.0 / 6.0);
         s = __builtin_fma(ax * x2, pl, ax);
     } else {
         s = 0.5 * (e - ei);
@@ -89,6 +87,15 @@ UCF_DEV cplx cinv_scaled(cplx z)
     const double c = ldexp(z.re, -il), d = ldexp(z.im, -il);
     const double r = fast_rcp(c * c + d * d);
     return cmake(ldexp(c * r, -il), ldexp(-(d * r), -il));
+}
+
+// 1/z: unscaled when every lane of the wave is far from overflow/underflow of |z|^2 (same bits either way:
+// the scaling is by powers of two)
+UCF_DEV cplx cinv_auto(cplx z)
+{
+    const double m = fmax(fabs(z.re), fabs(z.im));
+    if (__builtin_amdgcn_ballot_w64(!(m < 1.0e150 && m > 1.0e-150)) == 0) return cinv_plain(z);
+    return cinv_scaled(z);
 }
 
 struct lane_consts {     // per lane, constant over the abscissa loop of one point
@@ -130,9 +137,10 @@ UCF_DEV bool fast_prepare(const ucf_dev_params& P, const lane_consts& L, double 
     }
     {   // eta = sqrt(q/kappa), Re q > 0                                                         (:69,172)
         const double qr = q.re * P.inv_kappa, qi = q.im * P.inv_kappa;
-        const double d = sqrt(qr * qr + qi * qi);
-        const double r = sqrt(0.5 * (d + qr));
-        S.eta = cmake(r, 0.5 * qi * fast_rcp(r));
+        double d, r, hr;
+        sqrt_hrsqrt(__builtin_fma(qr, qr, qi * qi), &d, &hr);
+        sqrt_hrsqrt(0.5 * (d + qr), &r, &hr);
+        S.eta = cmake(r, qi * hr);
     }
     if (!(S.eta.re <= P.fast_eta_max) || !(q.re > 0.0)) return false;
     const bool hantush = !(FAMILY == 2 && P.model == 4);
@@ -148,7 +156,7 @@ UCF_DEV bool fast_prepare(const ucf_dev_params& P, const lane_consts& L, double 
         fprim pl;
         if (!z2) { pl = prim(S.eta.re * P.lD1, S.eta.im * P.lD1); S.ff2 = psinh(pl); }         // :177
         else S.ff2 = cmake(0.0, 0.0);
-        if (!(z1 && z2) || need_lay1) S.inv_she = cinv_scaled(S.she);
+        if (!(z1 && z2) || need_lay1) S.inv_she = cinv_auto(S.she);
         if (need_lay1) {                                                                        // :183-184
             const cplx exl = z2 ? cmake(1.0, 0.0) : pexpneg(pl);
             S.g3 = csub(exl, cmul(cadd(S.ff1, cmul(S.ex1, S.ff2)), S.inv_she));
@@ -171,8 +179,8 @@ UCF_DEV bool fast_prepare(const ucf_dev_params& P, const lane_consts& L, double 
         S.small_eta = S.eta.re < P.maxexp;                                                      // :84
         cplx one_bex = cmake(1.0, 0.0);
         if (P.beta != 0.0) one_bex = radd(1.0, cmul(rscale(P.beta, S.eta), xi));
-        if (S.small_eta) S.inv_den = cinv_scaled(cadd(cmul(one_bex, S.che), cmul(xi, S.she)));  // :86-87
-        else S.inv_den = cinv_scaled(cadd(one_bex, xi));                                        // :90-91
+        if (S.small_eta) S.inv_den = cinv_auto(cadd(cmul(one_bex, S.che), cmul(xi, S.she)));  // :86-87
+        else S.inv_den = cinv_auto(cadd(one_bex, xi));                                        // :90-91
     }
     if (FAMILY == 4) {
         // Mishra/Neuman finite-difference vadose zone (:444-544): sigma(1) of the tridiagonal system by

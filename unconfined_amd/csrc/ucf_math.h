@@ -93,6 +93,45 @@ UCF_DEV double fast_rcp(double x)
     r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
     return r;
 }
+
+// a*b + C, a*C and a + C with the 64-bit constant C held in an SGPR pair.  Left to itself the compiler
+// selects v_fmac_f64 for a Horner step and first copies the coefficient into the destination VGPR pair
+// (two v_mov_b32 per step: on CDNA every VALU instruction, a 32-bit move included, costs a full fp64 issue
+// slot, so the moves doubled the cost of every polynomial); s_mov_b32 runs on the scalar unit instead.
+UCF_DEV double fmak(double a, double b, double c)
+{
+    double o;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(o) : "v"(a), "v"(b), "s"(c));
+    return o;
+}
+UCF_DEV double mulk(double a, double c)
+{
+    double o;
+    asm("v_mul_f64 %0, %1, %2" : "=v"(o) : "v"(a), "s"(c));
+    return o;
+}
+UCF_DEV double addk(double a, double c)
+{
+    double o;
+    asm("v_add_f64 %0, %1, %2" : "=v"(o) : "v"(a), "s"(c));
+    return o;
+}
+// g = sqrt(x) and h = 1/(2 sqrt(x)) together, 1e-290 < x < 1e290 (no scaling): v_rsq_f64 estimate and two
+// coupled Newton steps on (g, h), then one correction of g.  g < 1 ulp, h ~ 1 ulp.
+UCF_DEV void sqrt_hrsqrt(double x, double* g_out, double* h_out)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    const double d = __builtin_fma(-g, g, x);
+    *g_out = __builtin_fma(d, h, g);
+    *h_out = h;
+}
 #endif
 
 // compiler-rt __divdc3
@@ -164,13 +203,13 @@ UCF_DEV void sincos_(double x, double* sn, double* cs)
     const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
                  S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
     const double v = z * y0;
-    const double rs = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
+    const double rs = fmak(z, fmak(z, fmak(z, addk(mulk(z, S6), S5), S4), S3), S2);
     const double ksin = y0 - ((z * (0.5 * y1 - v * rs) - y1) - v * S1);
     // __kernel_cos(y0, y1)  (msun form, branch free)
     const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
                  C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
     const double ww = z * z;
-    const double rc = z * (C1 + z * (C2 + z * C3)) + (ww * ww) * (C4 + z * (C5 + z * C6));
+    const double rc = __builtin_fma(ww * ww, fmak(z, addk(mulk(z, C6), C5), C4), z * fmak(z, addk(mulk(z, C3), C2), C1));
     const double hz = 0.5 * z;
     const double w1 = 1.0 - hz;
     const double kcos = w1 + (((1.0 - w1) - hz) + (z * rc - y0 * y1));

@@ -28,21 +28,21 @@ extern "C" int ucf_fp64_fma_peak(double* tflops)
     double* d = nullptr;
     if (hipMalloc((void**)&d, sizeof(double) * blocks * threads) != hipSuccess) return UCF_ERR_NOMEM;
     hipEvent_t e0, e1;
-    hipEventCreate(&e0); hipEventCreate(&e1);
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     hipLaunchKernelGGL(fma_chain, dim3(blocks), dim3(threads), 0, 0, d, 1.0);      // warm-up
     double best = 0.0;
     for (int rep = 0; rep < 5; rep++) {
-        hipEventRecord(e0, 0);
+        (void)hipEventRecord(e0, 0);
         hipLaunchKernelGGL(fma_chain, dim3(blocks), dim3(threads), 0, 0, d, 1.0 + rep);
-        hipEventRecord(e1, 0);
-        hipEventSynchronize(e1);
+        (void)hipEventRecord(e1, 0);
+        (void)hipEventSynchronize(e1);
         float ms = 0.f;
-        hipEventElapsedTime(&ms, e0, e1);
+        (void)hipEventElapsedTime(&ms, e0, e1);
         const double flops = 2.0 * 8.0 * ITER * (double)blocks * threads;
         const double tf = flops / (ms * 1e-3) * 1e-12;
         if (tf > best) best = tf;
     }
-    hipEventDestroy(e0); hipEventDestroy(e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     (void)hipFree(d);
     *tflops = best;
     return hipGetLastError() == hipSuccess ? UCF_OK : UCF_ERR_HIP;

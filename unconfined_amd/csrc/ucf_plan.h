@@ -71,6 +71,12 @@ struct ucf_plan {
     // finished J0-interval areas of the resident workgroups: [UCF_GRID_SLOTS][nacc][nz][64] complex
     double* d_glscr;
     size_t glscr_bytes;
+    // fast flavour: state of every work item between integrate_kernel and point_kernel
+    // [items][(R+1+nacc)*nz][64] complex, and the abscissae done per item
+    double* d_state;
+    size_t state_bytes;
+    int* d_ndone;
+    size_t ndone_items;
 };
 
 // launchers implemented in ucf_kernels.hip (one set per build flavour)
@@ -80,13 +86,13 @@ int launch_abscissae(const ucf_dev_params& dp, int nrows, int per_point, int nsv
                      const int* d_sv, double* d_tab, void* stream);
 int launch_points(const ucf_dev_params& dp, int npts, int per_point, int nr, int nsv, int svmin, const double* d_tD,
                   const double* d_rD, const int* d_sv, const double* d_tab, double* d_h, double* d_dh,
-                  ucf_stats* d_stats, void* stream, double* d_glscr);
+                  ucf_stats* d_stats, void* stream, double* d_glscr, double* d_state, int* d_ndone);
 int launch_points_chunked(const ucf_dev_params& dp, int npts, int per_point, int nr, int nsv, int svmin, const double* d_tD,
                           const double* d_rD, const int* d_sv, const double* d_tab, double* d_totlap, double* d_h,
-                          double* d_dh, ucf_stats* d_stats, void* stream, double* d_glscr);
+                          double* d_dh, ucf_stats* d_stats, void* stream, double* d_glscr, double* d_state, int* d_ndone);
 int launch_grid_transposed(const ucf_dev_params& dp, int nt, int nr, int ir0, int nrc, int svmin, const double* d_tD,
                            const double* d_rD, const double* d_tab, double* d_totlap, double* d_h, double* d_dh,
-                           ucf_stats* d_stats, void* stream, void* ev0, void* ev1, double* d_glscr);
+                           ucf_stats* d_stats, void* stream, void* ev0, void* ev1, double* d_glscr, double* d_state, int* d_ndone);
 int launch_samples(const ucf_dev_params& dp, int n_a, const double* d_a, double rD, const double* d_p, double* d_fp,
                    void* stream);
 int launch_bessel(int n, const double* d_z, double* d_k, int* d_ierr, void* stream);
@@ -98,13 +104,15 @@ int launch_extrap(int n, int R, const double* d_x, const double* d_y, double* d_
 namespace ucf_fast {
 int launch_points_chunked(const ucf_dev_params& dp, int npts, int per_point, int nr, int nsv, int svmin, const double* d_tD,
                           const double* d_rD, const int* d_sv, const double* d_tab, double* d_totlap, double* d_h,
-                          double* d_dh, ucf_stats* d_stats, void* stream, double* d_glscr);
+                          double* d_dh, ucf_stats* d_stats, void* stream, double* d_glscr, double* d_state, int* d_ndone);
 int launch_grid_transposed(const ucf_dev_params& dp, int nt, int nr, int ir0, int nrc, int svmin, const double* d_tD,
                            const double* d_rD, const double* d_tab, double* d_totlap, double* d_h, double* d_dh,
-                           ucf_stats* d_stats, void* stream, void* ev0, void* ev1, double* d_glscr);
+                           ucf_stats* d_stats, void* stream, void* ev0, void* ev1, double* d_glscr, double* d_state, int* d_ndone);
 int launch_points(const ucf_dev_params& dp, int npts, int per_point, int nr, int nsv, int svmin, const double* d_tD,
                   const double* d_rD, const int* d_sv, const double* d_tab, double* d_h, double* d_dh,
-                  ucf_stats* d_stats, void* stream, double* d_glscr);
+                  ucf_stats* d_stats, void* stream, double* d_glscr, double* d_state, int* d_ndone);
 int launch_samples(const ucf_dev_params& dp, int n_a, const double* d_a, double rD, const double* d_p, double* d_fp,
                    void* stream);
+// bytes of integrate_kernel -> point_kernel state per work item (0 where the flavour / model has no integrate_kernel)
+size_t state_bytes_per_item(const ucf_dev_params& dp);
 }
