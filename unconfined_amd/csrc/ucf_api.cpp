@@ -219,6 +219,17 @@ int fill_call_params(const ucf_plan* plan, int nz, const double* zD, const int* 
         dp.zD[i] = zD[i];
         dp.zLay[i] = zLay[i];
     }
+    // the fast evaluators take sin/cos of Im(eta)*c for c in {1, dD, 1-lD, dD1-1, zD, 1-zD, dD1-zD}:
+    // the largest |c| bounds the argument (two-stage Cody-Waite reduction is good below 1e6)
+    double cmax = 1.0;
+    const double cs[] = {dp.dD, dp.lD1, dp.dD1 - 1.0};
+    for (double c : cs) cmax = std::fmax(cmax, std::fabs(c));
+    for (int i = 0; i < nz; i++) {
+        cmax = std::fmax(cmax, std::fabs(zD[i]));
+        cmax = std::fmax(cmax, std::fabs(1.0 - zD[i]));
+        cmax = std::fmax(cmax, std::fabs(dp.dD1 - zD[i]));
+    }
+    dp.fast_im_max = 1.0e6 / cmax;
     return UCF_OK;
 }
 

@@ -944,6 +944,9 @@ integrate_kernel(const ucf_dev_params P, int npts, int per_point, int nr, int ns
                  const double2* __restrict__ tab, int nt, int ir0, double2* __restrict__ state, int* __restrict__ ndone)
 {
     extern __shared__ lds_c lds[];
+#ifdef UCF_K1_ASSUME
+    UCF_K1_ASSUME      // tools/: specialise a probe build to one plan shape to read its inner loop
+#endif
     const int lane = threadIdx.x;
     const int nz = P.nz, R = P.R, nacc = P.nacc, N = P.N, ngl = P.ngl;
     const int nabs = N + nacc * ngl;
@@ -972,8 +975,8 @@ integrate_kernel(const ucf_dev_params P, int npts, int per_point, int nr, int ns
         for (; n < nabs; n++) {
             const double2 aa = row[n];
             fast_common F;
-            const bool ok = fast_prepare<FAMILY>(P, LC, aa.x, need_lay1, F);
-            if (!__all(ok)) break;
+            if (!__all(fast_eta<FAMILY>(P, LC, aa.x, F))) break;
+            fast_common_terms<FAMILY>(P, LC, aa.x, need_lay1, F);
             for (int z = 0; z < nz; z++) {
                 // val = a*J0(a rD) * f(a,p,z) * lapTime(p)                                      (lhs.f90:118)
                 const cplx val = cmul(rscale(aa.y, fast_sample_z<FAMILY>(P, F, z)), lt);

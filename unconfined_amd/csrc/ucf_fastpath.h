@@ -65,7 +65,7 @@ UCF_DEV fprim prim(double x, double y)
         s = 0.5 * (e - ei);
     }
     f.sh = copysign(s, x);
-    sincos_(y, &f.sn, &f.cs);
+    sincos_medium_(y, &f.sn, &f.cs);     // |y| < 1e6: fast_eta() vouches for it
     return f;
 }
 UCF_DEV cplx pcosh(const fprim& f) { return cmake(f.ch * f.cs, f.sh * f.sn); }
@@ -125,9 +125,11 @@ struct fast_common {
     bool small_eta, fd_use;
 };
 
-// z-independent part.  Returns false (for this lane) if the fast evaluation is not applicable.
+// theta and eta of this abscissa.  Returns false (for this lane) if the fast evaluation is not applicable:
+// a cosh/sinh could overflow, or the argument of a sin/cos (|Im eta| times a factor <= 1) leaves the range of
+// the two-stage Cody-Waite reduction.
 template <int FAMILY>
-UCF_DEV bool fast_prepare(const ucf_dev_params& P, const lane_consts& L, double a, bool need_lay1, fast_common& S)
+UCF_DEV bool fast_eta(const ucf_dev_params& P, const lane_consts& L, double a, fast_common& S)
 {
     const double a2 = a * a;
     const cplx q = caddr(L.p, a2);
@@ -142,7 +144,14 @@ UCF_DEV bool fast_prepare(const ucf_dev_params& P, const lane_consts& L, double 
         sqrt_hrsqrt(0.5 * (d + qr), &r, &hr);
         S.eta = cmake(r, qi * hr);
     }
-    if (!(S.eta.re <= P.fast_eta_max) || !(q.re > 0.0)) return false;
+    return (S.eta.re <= P.fast_eta_max) && (q.re > 0.0) && (fabs(S.eta.im) < P.fast_im_max);
+}
+
+// z-independent part (after fast_eta said yes for every lane of the wave)
+template <int FAMILY>
+UCF_DEV void fast_common_terms(const ucf_dev_params& P, const lane_consts& L, double a, bool need_lay1, fast_common& S)
+{
+    const double a2 = a * a;
     const bool hantush = !(FAMILY == 2 && P.model == 4);
     const fprim p1 = prim(S.eta.re, S.eta.im);
     S.che = pcosh(p1);
@@ -207,6 +216,13 @@ UCF_DEV bool fast_prepare(const ucf_dev_params& P, const lane_consts& L, double 
         S.fd_s1 = cmul(v1p, cinv_scaled(B1p));
         S.fd_use = (fabs(S.fd_s1.re) + fabs(S.fd_s1.im)) > 2.3e-308;                            // :521
     }
+}
+
+template <int FAMILY>
+UCF_DEV bool fast_prepare(const ucf_dev_params& P, const lane_consts& L, double a, bool need_lay1, fast_common& S)
+{
+    if (!fast_eta<FAMILY>(P, L, a, S)) return false;
+    fast_common_terms<FAMILY>(P, L, a, need_lay1, S);
     return true;
 }
 
@@ -236,6 +252,7 @@ UCF_DEV cplx fast_hantush_z(const ucf_dev_params& P, const fast_common& S, doubl
             g2 = cmul(num, S.inv_she);                                                          // :179-180
         }
         if (lay == 2) {
+            if (z1 && z2) return cscale(S.th, P.inv_bD);                                        // g2 = 0: udp = 1
             udp = rsub(1.0, g2);                                                                // :192
         } else {
             const double c = P.dD1 - zD;

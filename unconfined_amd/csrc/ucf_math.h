@@ -100,6 +100,9 @@ UCF_DEV double fast_rcp(double x)
 // slot, so the moves doubled the cost of every polynomial); s_mov_b32 runs on the scalar unit instead.
 UCF_DEV double fmak(double a, double b, double c)
 {
+#ifdef UCF_NO_SGPR_CONSTANTS
+    return __builtin_fma(a, b, c);
+#endif
     double o;
     asm("v_fma_f64 %0, %1, %2, %3" : "=v"(o) : "v"(a), "v"(b), "s"(c));
     return o;
@@ -182,14 +185,9 @@ UCF_DEV bool c_is_finite(cplx z)
 // __kernel_sin / __kernel_cos on the reduced (head, tail).  < 1 ulp.  Larger arguments go to libm.
 __device__ __noinline__ static double2 sincos_huge_(double y) { double s, c; sincos(y, &s, &c); return make_double2(s, c); }
 
-UCF_DEV void sincos_(double x, double* sn, double* cs)
+// |x| < 1e6 (the caller's business)
+UCF_DEV void sincos_medium_(double x, double* sn, double* cs)
 {
-    if (__builtin_expect(!(fabs(x) < 1.0e6), 0)) {     // also NaN/Inf
-        const double2 sc = sincos_huge_(x);
-        *sn = sc.x;
-        *cs = sc.y;
-        return;
-    }
     const double fn = __builtin_rint(x * 6.36619772367581382433e-01);
     double r = __builtin_fma(-fn, 1.57079632673412561417e+00, x);          // exact (33-bit constant)
     const double t = r;
@@ -218,6 +216,16 @@ UCF_DEV void sincos_(double x, double* sn, double* cs)
     const double c_sel = (q & 1) ? ksin : kcos;
     *sn = (q & 2) ? -s_sel : s_sel;
     *cs = ((q + 1) & 2) ? -c_sel : c_sel;
+}
+UCF_DEV void sincos_(double x, double* sn, double* cs)
+{
+    if (__builtin_expect(!(fabs(x) < 1.0e6), 0)) {     // also NaN/Inf
+        const double2 sc = sincos_huge_(x);
+        *sn = sc.x;
+        *cs = sc.y;
+        return;
+    }
+    sincos_medium_(x, sn, cs);
 }
 #else
 // the faithful flavour calls the device libm; out of line to keep the kernels' code small

@@ -21,7 +21,7 @@ struct ucf_dev_params {
     double MoenchInvGamma[UCF_MAX_MOENCH];    // 1.0/gamma_m (:74)
     double alpha, logtol, maxexp;
     // fast flavour: hoisted reciprocals, plan-level exact folds, validity bound of the fast evaluation
-    double inv_kappa, inv_bD, fast_eta_max;
+    double inv_kappa, inv_bD, fast_eta_max, fast_im_max;
     int fold_dD, fold_lD1, share_g1top, _pad2;
     // Hantush with wellbore storage (:204-301): rDw, CDw (:250), tDb (:253)
     double hs_rDw, hs_CDw, hs_tDb;
