@@ -20,6 +20,7 @@
 #include "ucf_plan.h"
 
 // resident-workgroup budget: 256 CUs x 32 single-wave workgroups (only used when the interval areas live in global scratch, nz > 1); UCF_GRID_SLOTS in the environment overrides (tuning)
+int ucf_finish_part = [] { const char* e = std::getenv("UCF_FINISH_PART"); return e ? std::atoi(e) : 0; }();
 int ucf_grid_slots = [] { const char* e = std::getenv("UCF_GRID_SLOTS"); int v = e ? std::atoi(e) : 8192; return v > 0 ? v : 8192; }();
 
 namespace {
@@ -581,9 +582,9 @@ int ensure_state(ucf_plan* pl, const ucf_dev_params& dp, size_t items)
         if (hipMalloc((void**)&pl->d_state, need) != hipSuccess) return fail(UCF_ERR_NOMEM, "hipMalloc of %zu integration-state bytes failed", need);
         pl->state_bytes = need;
     }
-    if (pl->ndone_items < items) {
+    if (pl->ndone_items < items) {      // [done per item | count of unfinished | unfinished items]
         if (pl->d_ndone) { (void)hipDeviceSynchronize(); (void)hipFree(pl->d_ndone); pl->d_ndone = nullptr; pl->ndone_items = 0; }
-        if (hipMalloc((void**)&pl->d_ndone, items * sizeof(int)) != hipSuccess) return fail(UCF_ERR_NOMEM, "hipMalloc of %zu counters failed", items);
+        if (hipMalloc((void**)&pl->d_ndone, (2 * items + 1) * sizeof(int)) != hipSuccess) return fail(UCF_ERR_NOMEM, "hipMalloc of %zu counters failed", items);
         pl->ndone_items = items;
     }
     return UCF_OK;

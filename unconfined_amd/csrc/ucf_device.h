@@ -46,8 +46,11 @@ UCF_DEV void lds_st(lds_c* base, int slot, int lane, cplx z) { base[slot * UCF_W
 // scratch columns hold UCF_PART lanes per slot: the per-lane tails (Neville, Wynn) run on one
 // quarter-wave at a time, which quarters their LDS footprint at ~2 % of the point's time
 #define UCF_PART 16
-UCF_DEV cplx scr_ld(const lds_c* base, int slot, int lane) { lds_c v = base[slot * UCF_PART + (lane & (UCF_PART - 1))]; return cmake(v.x, v.y); }
-UCF_DEV void scr_st(lds_c* base, int slot, int lane, cplx z) { base[slot * UCF_PART + (lane & (UCF_PART - 1))] = make_double2(z.re, z.im); }
+// (finish_kernel picks wider parts when its LDS budget allows: PART lanes work at a time, 64/PART turns)
+template <int PART = UCF_PART>
+UCF_DEV cplx scr_ld(const lds_c* base, int slot, int lane) { lds_c v = base[slot * PART + (lane & (PART - 1))]; return cmake(v.x, v.y); }
+template <int PART = UCF_PART>
+UCF_DEV void scr_st(lds_c* base, int slot, int lane, cplx z) { base[slot * PART + (lane & (PART - 1))] = make_double2(z.re, z.im); }
 
 #if UCF_FAST
 // 1/z without exponent scaling (|z| well inside [1e-150, 1e150])
@@ -595,29 +598,29 @@ UCF_DEV double dehoog_wave2(const cplx (&f)[2], int M, double alpha, double logt
 // Per-lane Wynn-epsilon on two quarter-wave LDS scratch columns: colA[i] holds series(i+1) on entry
 // (overwritten by the even epsilon columns), colB the odd columns.
 // status: 0 ok, 1 truncated, 2 sentinel, 3 early exit.
-template <bool CUR_IS_A>
+template <bool CUR_IS_A, int PART = UCF_PART>
 UCF_DEV bool wynn_column(lds_c* colA, lds_c* colB, int count, int lane, cplx* acc)
 {
     // new(m) = prev(m+1) + 1/(cur(m+1) - cur(m)), m = 1..count; new column overwrites prev storage
     lds_c* cur = CUR_IS_A ? colA : colB;
     lds_c* prv = CUR_IS_A ? colB : colA;
     for (int m = 1; m <= count; m++) {
-        const cplx hi = scr_ld(cur, m, lane);
-        const cplx lo = scr_ld(cur, m - 1, lane);
+        const cplx hi = scr_ld<PART>(cur, m, lane);
+        const cplx lo = scr_ld<PART>(cur, m - 1, lane);
         const cplx denom = csub(hi, lo);
 #if UCF_FAST
         // |denom| > eps  <=>  |denom|^2 > eps^2 (no hypot), and 1/denom = conj(denom)/|denom|^2 reuses it
         const double d2 = __builtin_fma(denom.re, denom.re, denom.im * denom.im);
         if (d2 > UCF_EPS * UCF_EPS && d2 < 1.0e300) {
             const double r = fast_rcp(d2);
-            const cplx pv = scr_ld(prv, m, lane);
-            scr_st(prv, m - 1, lane, cmake(__builtin_fma(denom.re, r, pv.re), __builtin_fma(-denom.im, r, pv.im)));
+            const cplx pv = scr_ld<PART>(prv, m, lane);
+            scr_st<PART>(prv, m - 1, lane, cmake(__builtin_fma(denom.re, r, pv.re), __builtin_fma(-denom.im, r, pv.im)));
         } else if (cabs_(denom) > UCF_EPS) {                 // huge or non-finite difference: exact reference path
-            scr_st(prv, m - 1, lane, cadd(scr_ld(prv, m, lane), rdiv(1.0, denom)));
+            scr_st<PART>(prv, m - 1, lane, cadd(scr_ld<PART>(prv, m, lane), rdiv(1.0, denom)));
         } else {
 #else
         if (cabs_(denom) > UCF_EPS) {                                                           // :172
-            scr_st(prv, m - 1, lane, cadd(scr_ld(prv, m, lane), rdiv(1.0, denom)));             // :173
+            scr_st<PART>(prv, m - 1, lane, cadd(scr_ld<PART>(prv, m, lane), rdiv(1.0, denom)));             // :173
         } else {
 #endif
             *acc = hi;                                                                          // :175
@@ -627,34 +630,35 @@ UCF_DEV bool wynn_column(lds_c* colA, lds_c* colB, int count, int lane, cplx* ac
     return false;
 }
 
+template <int PART = UCF_PART>
 UCF_DEV cplx wynn_lane(lds_c* colA, lds_c* colB, int nin, int lane, int* status)
 {
     int ns = nin;
     int stat = 0;
     cplx run = cmake(0.0, 0.0);
     for (int i = 1; i <= nin; i++) {                                                            // :140-163
-        cplx s = scr_ld(colA, i - 1, lane);
+        cplx s = scr_ld<PART>(colA, i - 1, lane);
         if (!c_is_finite(s)) {
             ns = i - 1;
             stat = (ns < 4) ? 2 : 1;
             break;
         }
         run = (i == 1) ? s : cadd(run, s);
-        scr_st(colA, i - 1, lane, run);
+        scr_st<PART>(colA, i - 1, lane, run);
     }
     if (stat == 2) {
         *status = 2;
         return cmake((double)(-999999.9f), 0.0);                                                // :148
     }
-    for (int m = 0; m < ns; m++) scr_st(colB, m, lane, cmake(0.0, 0.0));                        // :166
+    for (int m = 0; m < ns; m++) scr_st<PART>(colB, m, lane, cmake(0.0, 0.0));                        // :166
     cplx acc = cmake(0.0, 0.0);
     bool done = false;
     for (int j = 0; j <= ns - 2 && !done; j++) {                                                // :169-181
         const int count = ns - (j + 1);
-        done = (j & 1) ? wynn_column<false>(colA, colB, count, lane, &acc) : wynn_column<true>(colA, colB, count, lane, &acc);
+        done = (j & 1) ? wynn_column<false, PART>(colA, colB, count, lane, &acc) : wynn_column<true, PART>(colA, colB, count, lane, &acc);
         if (done) stat = 3;
     }
-    if (!done) acc = scr_ld(colA, 1, lane);   // eps(2,ns-2) [ns even] or eps(2,ns-3) [ns odd]: both even columns
+    if (!done) acc = scr_ld<PART>(colA, 1, lane);   // eps(2,ns-2) [ns even] or eps(2,ns-3) [ns odd]: both even columns
     *status = stat;
     return acc;
 }
@@ -662,27 +666,28 @@ UCF_DEV cplx wynn_lane(lds_c* colA, lds_c* colB, int nin, int lane, int* status)
 // ------------------------------------------------------------- integration.f90:192-237
 // Per-lane Neville extrapolation to x = 0.  colC[(i*strideC)][lane] holds y(i+1) (destroyed),
 // colD is half-wave scratch.  x is wave-uniform.
+template <int PART = UCF_PART>
 UCF_DEV cplx extrap_lane(lds_c* colC, int strideC, lds_c* colD, const double* x, int n, int lane)
 {
     int ns = 1;
     for (int i = 2; i <= n; i++) if (x[i - 1] < x[ns - 1]) ns = i;                              // minloc
-    for (int i = 0; i < n; i++) scr_st(colD, i, lane, lds_ld(colC, i * strideC, lane));
+    for (int i = 0; i < n; i++) scr_st<PART>(colD, i, lane, lds_ld(colC, i * strideC, lane));
     cplx y = lds_ld(colC, (ns - 1) * strideC, lane);
     ns = ns - 1;
     for (int m = 1; m <= n - 1; m++) {
         for (int i = 1; i <= n - m; i++) {
             const double dx = x[i - 1] - x[i + m - 1];
             cplx ci = lds_ld(colC, i * strideC, lane);
-            cplx di = scr_ld(colD, i - 1, lane);
+            cplx di = scr_ld<PART>(colD, i - 1, lane);
             cplx den = cdiv(csub(ci, di), cmake(dx, 0.0));                                      // :227 (complex/complex)
-            scr_st(colD, i - 1, lane, rscale(x[i + m - 1], den));
+            scr_st<PART>(colD, i - 1, lane, rscale(x[i + m - 1], den));
             lds_st(colC, (i - 1) * strideC, lane, rscale(x[i - 1], den));
         }
         cplx dy;
         if (2 * ns < n - m) {
             dy = lds_ld(colC, ns * strideC, lane);
         } else {
-            dy = scr_ld(colD, ns - 1, lane);
+            dy = scr_ld<PART>(colD, ns - 1, lane);
             ns = ns - 1;
         }
         y = cadd(y, dy);
@@ -778,6 +783,70 @@ UCF_DEV work_item decode_item(const ucf_dev_params& P, int pt, int lane, int per
     return W;
 }
 
+// ------------------------------------------------------------------ the tail of a work item
+// driver.f90:159-230 per depth: scale the level sums, Richardson/Neville to h -> 0, Wynn-epsilon over the
+// J0-interval areas, then the transform goes to the workspace (LAYOUT 1, 2) or straight through de Hoog
+// (LAYOUT 0).  accTS: [R][nz] level sums in LDS; the finished areas come from LDS (accGL) or global memory.
+// PART lanes of the wave work at a time on the scratch columns scr ([max(2 nacc, R)][PART]).
+template <int LAYOUT, int PART>
+UCF_DEV void finish_item(const ucf_dev_params& P, lds_c* accTS, lds_c* scr, const lds_c* accGL,
+                         const double2* __restrict__ areas, double arg, const work_item& W, int pt, double tD, double tee,
+                         cplx p, ucf_stats* st, int nt, int ir0, double2* __restrict__ totlap, double* __restrict__ hout,
+                         double* __restrict__ dhout)
+{
+    const int lane = threadIdx.x;
+    const int nz = P.nz, R = P.R, nacc = P.nacc;
+    for (int z = 0; z < nz; z++) {
+        for (int j = 0; j < R; j++) {
+            const int slot = j * nz + z;
+            lds_st(accTS, slot, lane, rscale(arg / 2.0, lds_ld(accTS, slot, lane)));            // :135,154
+        }
+        bool any = false;
+        cplx finint = lds_ld(accTS, z, lane);
+        cplx infint = cmake(0.0, 0.0);
+        int wst = 0;
+        for (int part = 0; part < UCF_WAVE / PART; part++) {
+            if ((lane / PART) == part) {
+                if (R > 1) finint = extrap_lane<PART>(accTS + (size_t)z * UCF_WAVE, nz, scr, P.hv, R, lane);
+                lds_c* colA = scr;
+                lds_c* colB = scr + (size_t)nacc * PART;
+                for (int jj = 0; jj < nacc; jj++) {
+                    cplx ar;
+                    if (accGL) {
+                        ar = lds_ld(accGL, jj * nz + z, lane);
+                    } else {
+                        const double2 v = areas[(size_t)(jj * nz + z) * UCF_WAVE + lane];
+                        ar = cmake(v.x, v.y);
+                    }
+                    any |= (cabs_(ar) > 0.0);                                                   // :209
+                    scr_st<PART>(colA, jj, lane, ar);
+                }
+                if (any) infint = wynn_lane<PART>(colA, colB, nacc, lane, &wst);
+            }
+        }
+        if (st) {
+            stat_add(&st->wynn_all_zero, W.live && !any);
+            stat_add(&st->wynn_truncated, W.live && wst == 1);
+            stat_add(&st->wynn_sentinel, W.live && wst == 2);
+            stat_add(&st->wynn_early_exit, W.live && wst == 3);
+        }
+        const cplx tl = cadd(finint, infint);                                                   // :216
+        if (LAYOUT == 1) {
+            // [radius of the chunk][z][m][time]: the 64 lanes (consecutive times) store 1 KB contiguously
+            if (W.live) totlap[(((size_t)(W.ir - ir0) * nz + z) * P.np + W.mlap) * nt + W.it] = make_double2(tl.re, tl.im);
+        } else if (LAYOUT == 2) {
+            if (W.live) totlap[((size_t)W.pidx * nz + z) * P.np + W.mlap] = make_double2(tl.re, tl.im);
+        } else {
+            const double hval = dehoog_wave(tl, P.M, P.alpha, P.logtol, tD, tee, lane, st);      // :219-223
+            const double dval = dehoog_wave(cmul(tl, p), P.M, P.alpha, P.logtol, tD, tee, lane, st) * tD;   // :225-230
+            if (lane == 0) {
+                hout[(size_t)pt * P.nz_out + P.z_off + z] = hval;
+                dhout[(size_t)pt * P.nz_out + P.z_off + z] = dval;
+            }
+        }
+    }
+}
+
 // State handed from integrate_kernel to point_kernel (fast flavour): per work item
 // [(R + 1 + nacc) * nz][64] complex = level sums | area of the interval in progress | finished areas,
 // plus the number of abscissae already integrated.
@@ -789,7 +858,7 @@ point_kernel(const ucf_dev_params P, int npts, int per_point, int nr, int nsv, i
              const double* __restrict__ tDv, const double* __restrict__ rDv, const int* __restrict__ svv,
              const double2* __restrict__ tab, double* __restrict__ hout, double* __restrict__ dhout, ucf_stats* st,
              int nt, int ir0, int nrc, double2* __restrict__ totlap, double2* __restrict__ glscr,
-             double2* __restrict__ state, const int* __restrict__ ndone)
+             double2* __restrict__ state, const int* __restrict__ ndone, const int* __restrict__ todo)
 {
     extern __shared__ lds_c lds[];
     const int lane = threadIdx.x;
@@ -801,8 +870,10 @@ point_kernel(const ucf_dev_params P, int npts, int per_point, int nr, int nsv, i
     lds_c* accGL = scr + (size_t)(2 * nacc > R ? 2 * nacc : R) * UCF_PART;   // [nacc][nz] finished areas (if kept in LDS)
     // finished interval areas: in LDS while that does not cost occupancy (nz = 1), else in an L2-resident
     // global scratch slot of this (then persistent, grid-strided) workgroup: [nacc][nz][64] complex;
-    // when resuming after integrate_kernel they stay where that kernel put them (the item's state)
+    // when resuming after integrate_kernel they stay where that kernel put them (the item's state), and the
+    // items are the ones that kernel listed as unfinished: todo = [count | item, item, ...]
     const bool resume = (state != nullptr);
+    const int nloop = resume ? todo[0] : npts;
     const bool areas_lds = (glscr == nullptr) && !resume;
     lds_c* fdbuf = accGL + (areas_lds ? (size_t)nacc * nz * UCF_WAVE : 0);
     double2* __restrict__ areas = areas_lds ? nullptr : glscr + (size_t)blockIdx.x * nacc * nz * UCF_WAVE;
@@ -810,10 +881,10 @@ point_kernel(const ucf_dev_params P, int npts, int per_point, int nr, int nsv, i
     bool need_lay1 = false;
     for (int z = 0; z < nz; z++) need_lay1 |= (P.zLay[z] == 1);
 
-    for (int pt = blockIdx.x; pt < npts; pt += gridDim.x) {
+    for (int wi = blockIdx.x; wi < nloop; wi += gridDim.x) {
+        const int pt = resume ? todo[1 + wi] : wi;
         const work_item W = decode_item<LAYOUT>(P, pt, lane, per_point, nr, nt, ir0);
         const int it = W.it, ir = W.ir, mlap = W.mlap, pidx = W.pidx;
-        const bool live = W.live;
         const double tD = tDv[it], rD = rDv[ir];
         const int sv = (LAYOUT == 1) ? svmin : svv[it];
         const double2* __restrict__ row = tab + (size_t)(per_point ? pidx : (ir * nsv + (sv - svmin))) * nabs;
@@ -871,56 +942,8 @@ point_kernel(const ucf_dev_params P, int npts, int per_point, int nr, int nsv, i
             sample_prepare<FAMILY>(P, aa.x, p, need_lay1, S, fdbuf, lane, lane_aux);
             for (int z = 0; z < nz; z++) accumulate(n, aa.y, z, sample_z<FAMILY>(P, S, z));
         }
-        // ---- per depth: Richardson, Wynn-epsilon, de Hoog (:159-230)
-        for (int z = 0; z < nz; z++) {
-            for (int j = 0; j < R; j++) {
-                const int slot = j * nz + z;
-                lds_st(accTS, slot, lane, rscale(arg / 2.0, lds_ld(accTS, slot, lane)));        // :135,154
-            }
-            bool any = false;
-            cplx finint = lds_ld(accTS, z, lane);
-            cplx infint = cmake(0.0, 0.0);
-            int wst = 0;
-            for (int part = 0; part < UCF_WAVE / UCF_PART; part++) {
-                if ((lane / UCF_PART) == part) {
-                    if (R > 1) finint = extrap_lane(accTS + (size_t)z * UCF_WAVE, nz, scr, P.hv, R, lane);
-                    lds_c* colA = scr;
-                    lds_c* colB = scr + (size_t)nacc * UCF_PART;
-                    for (int jj = 0; jj < nacc; jj++) {
-                        cplx ar;
-                        if (areas_lds) {
-                            ar = lds_ld(accGL, jj * nz + z, lane);
-                        } else {
-                            const double2 v = areas[(size_t)(jj * nz + z) * UCF_WAVE + lane];
-                            ar = cmake(v.x, v.y);
-                        }
-                        any |= (cabs_(ar) > 0.0);                                               // :209
-                        scr_st(colA, jj, lane, ar);
-                    }
-                    if (any) infint = wynn_lane(colA, colB, nacc, lane, &wst);
-                }
-            }
-            if (st) {
-                stat_add(&st->wynn_all_zero, live && !any);
-                stat_add(&st->wynn_truncated, live && wst == 1);
-                stat_add(&st->wynn_sentinel, live && wst == 2);
-                stat_add(&st->wynn_early_exit, live && wst == 3);
-            }
-            const cplx tl = cadd(finint, infint);                                               // :216
-            if (LAYOUT == 1) {
-                // [radius of the chunk][z][m][time]: the 64 lanes (consecutive times) store 1 KB contiguously
-                if (live) totlap[(((size_t)(ir - ir0) * nz + z) * P.np + mlap) * nt + it] = make_double2(tl.re, tl.im);
-            } else if (LAYOUT == 2) {
-                if (live) totlap[((size_t)pidx * nz + z) * P.np + mlap] = make_double2(tl.re, tl.im);
-            } else {
-                const double hval = dehoog_wave(tl, P.M, P.alpha, P.logtol, tD, tee, lane, st);  // :219-223
-                const double dval = dehoog_wave(cmul(tl, p), P.M, P.alpha, P.logtol, tD, tee, lane, st) * tD;   // :225-230
-                if (lane == 0) {
-                    hout[(size_t)pt * P.nz_out + P.z_off + z] = hval;
-                    dhout[(size_t)pt * P.nz_out + P.z_off + z] = dval;
-                }
-            }
-        }
+        finish_item<LAYOUT, UCF_PART>(P, accTS, scr, areas_lds ? accGL : nullptr, areas, arg, W, pt, tD, tee, p, st, nt, ir0, totlap,
+                                      hout, dhout);
     }
 }
 
@@ -941,7 +964,8 @@ template <int FAMILY, int LAYOUT>
 __global__ void __launch_bounds__(UCF_WAVE, UCF_INTEGRATE_WAVES)
 integrate_kernel(const ucf_dev_params P, int npts, int per_point, int nr, int nsv, int svmin,
                  const double* __restrict__ tDv, const double* __restrict__ rDv, const int* __restrict__ svv,
-                 const double2* __restrict__ tab, int nt, int ir0, double2* __restrict__ state, int* __restrict__ ndone)
+                 const double2* __restrict__ tab, int nt, int ir0, double2* __restrict__ state, int* __restrict__ ndone,
+                 int* __restrict__ todo)
 {
     extern __shared__ lds_c lds[];
 #ifdef UCF_K1_ASSUME
@@ -1007,7 +1031,43 @@ integrate_kernel(const ucf_dev_params P, int npts, int per_point, int nr, int ns
             }
         }
         for (int s = 0; s < (R + 1) * nz; s++) sti[(size_t)s * UCF_WAVE + lane] = lds[s * UCF_WAVE + lane];
-        if (lane == 0) ndone[pt] = n;
+        if (lane == 0) {
+            ndone[pt] = n;
+            if (n < nabs) todo[1 + atomicAdd(&todo[0], 1)] = pt;      // point_kernel takes it from here
+        }
+    }
+}
+
+// ------------------------------------------------------------------ the finishing kernel (fast flavour)
+// Tail of every work item integrate_kernel completed (all of them outside the overflow regime): state ->
+// finish_item.  Model independent and small, so it runs at full occupancy; PART is chosen at launch from the
+// LDS footprint ((R+1) nz slots of level sums + max(2 nacc, R) scratch columns of PART lanes).
+template <int LAYOUT, int PART>
+__global__ void __launch_bounds__(UCF_WAVE, LAYOUT == 0 ? 3 : 4)      // LAYOUT 0 carries de Hoog
+finish_kernel(const ucf_dev_params P, int npts, int per_point, int nr, int nsv, int svmin,
+              const double* __restrict__ tDv, const double* __restrict__ rDv, const int* __restrict__ svv,
+              double* __restrict__ hout, double* __restrict__ dhout, ucf_stats* st, int nt, int ir0,
+              double2* __restrict__ totlap, const double2* __restrict__ state, const int* __restrict__ ndone)
+{
+    extern __shared__ lds_c lds[];
+    const int lane = threadIdx.x;
+    const int nz = P.nz, R = P.R, nacc = P.nacc;
+    const int nabs = P.N + nacc * P.ngl;
+    lds_c* accTS = lds;
+    lds_c* scr = lds + (size_t)R * nz * UCF_WAVE;
+    for (int pt = blockIdx.x; pt < npts; pt += gridDim.x) {
+        if (ndone[pt] < nabs) continue;
+        const work_item W = decode_item<LAYOUT>(P, pt, lane, per_point, nr, nt, ir0);
+        const double tD = tDv[W.it], rD = rDv[W.ir];
+        const int sv = (LAYOUT == 1) ? svmin : svv[W.it];
+        const double tee = 2.0 * tD;
+        const double sigma = P.alpha - P.logtol / (2.0 * tee);
+        const cplx p = cmake(sigma, UCF_PI * W.mlap / tee);
+        const double arg = P.j0z[sv - 1] / rD;                                                  // driver.f90:120
+        const double2* __restrict__ sti = state + (size_t)pt * state_slots(P) * UCF_WAVE;
+        for (int s = 0; s < R * nz; s++) lds[s * UCF_WAVE + lane] = sti[(size_t)s * UCF_WAVE + lane];
+        finish_item<LAYOUT, PART>(P, accTS, scr, nullptr, sti + (size_t)(R + 1) * nz * UCF_WAVE, arg, W, pt, tD, tee, p, st, nt, ir0,
+                                  totlap, hout, dhout);
     }
 }
 #endif
@@ -1306,6 +1366,7 @@ static int launch_transform(const ucf_dev_params& dp, int nwork, int per_point, 
                             ucf_stats* d_stats, int nt, int ir0, int nrc, double* d_totlap, double* d_glscr,
                             double* d_state, int* d_ndone, void* stream, void* ev0, void* ev1)
 {
+    int* d_todo = d_ndone ? d_ndone + nwork : nullptr;     // [count | items]: the caller sizes d_ndone for 2 nwork + 1 ints
     const int fam = family_of(dp);
     if (fam < 0) return UCF_ERR_UNSUPPORTED;
     const bool split = split_integration(dp);
@@ -1315,18 +1376,19 @@ static int launch_transform(const ucf_dev_params& dp, int nwork, int per_point, 
     hipStream_t s = (hipStream_t)stream;
     const bool al = areas_in_lds(dp) || split;
     if (al) d_glscr = nullptr;
-    if (!split) { d_state = nullptr; d_ndone = nullptr; }
+    if (!split) { d_state = nullptr; d_ndone = nullptr; d_todo = nullptr; }
     dim3 grid((unsigned)((al || nwork < UCF_GRID_SLOTS) ? nwork : UCF_GRID_SLOTS)), block(UCF_WAVE);
 #if UCF_FAST
     if (split) {
         const size_t ilds = (size_t)(dp.R + 1) * dp.nz * UCF_WAVE * sizeof(lds_c);
+        (void)hipMemsetAsync(d_todo, 0, sizeof(int), s);
         if (ev0) (void)hipEventRecord((hipEvent_t)ev0, s);
 #define UCF_LAUNCH_I(F)                                                                                        \
     do {                                                                                                       \
         if (ilds > 64 * 1024)                                                                                  \
             (void)hipFuncSetAttribute((const void*)integrate_kernel<F, LAYOUT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ilds); \
         hipLaunchKernelGGL((integrate_kernel<F, LAYOUT>), dim3((unsigned)nwork), block, ilds, s, dp, nwork, per_point, nr, nsv, svmin, \
-                           d_tD, d_rD, d_sv, (const double2*)d_tab, nt, ir0, (double2*)d_state, d_ndone);      \
+                           d_tD, d_rD, d_sv, (const double2*)d_tab, nt, ir0, (double2*)d_state, d_ndone, d_todo); \
     } while (0)
         switch (fam) {
         case 1: UCF_LAUNCH_I(1); break;
@@ -1337,6 +1399,29 @@ static int launch_transform(const ucf_dev_params& dp, int nwork, int per_point, 
         if (ev1) (void)hipEventRecord((hipEvent_t)ev1, s);
         if (hipGetLastError() != hipSuccess) return UCF_ERR_HIP;
         ev0 = ev1 = nullptr;
+        // tails of the completed items: the widest scratch part that still leaves 4 waves per CU (measured on C2:
+        // 4.8 / 3.6 / 3.1 ms for parts of 16 / 32 / 64 lanes)
+        const size_t scols = (size_t)(2 * dp.nacc > dp.R ? 2 * dp.nacc : dp.R);
+        auto flds = [&](int part) { return ((size_t)dp.R * dp.nz * UCF_WAVE + scols * part) * sizeof(lds_c); };
+        int part = ucf_finish_part;
+        if (part != 16 && part != 32 && part != 64) part = (flds(64) <= 40 * 1024) ? 64 : (flds(32) <= 40 * 1024) ? 32 : 16;
+        const size_t fl = flds(part);
+        if (fl > 160 * 1024) return UCF_ERR_UNSUPPORTED;
+#define UCF_LAUNCH_F(PART)                                                                                     \
+    do {                                                                                                       \
+        if (fl > 64 * 1024)                                                                                    \
+            (void)hipFuncSetAttribute((const void*)finish_kernel<LAYOUT, PART>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fl); \
+        hipLaunchKernelGGL((finish_kernel<LAYOUT, PART>), dim3((unsigned)nwork), block, fl, s, dp, nwork, per_point, nr, nsv, svmin, \
+                           d_tD, d_rD, d_sv, d_h, d_dh, d_stats, nt, ir0, (double2*)d_totlap, (const double2*)d_state, \
+                           (const int*)d_ndone);                                                               \
+    } while (0)
+        if (part == 64) UCF_LAUNCH_F(64);
+        else if (part == 32) UCF_LAUNCH_F(32);
+        else UCF_LAUNCH_F(16);
+#undef UCF_LAUNCH_F
+        if (hipGetLastError() != hipSuccess) return UCF_ERR_HIP;
+        // the unfinished ones (overflow regime): point_kernel over the list integrate_kernel left
+        grid = dim3((unsigned)(nwork < 2048 ? nwork : 2048));
     }
 #endif
     if (ev0) (void)hipEventRecord((hipEvent_t)ev0, s);
@@ -1346,7 +1431,7 @@ static int launch_transform(const ucf_dev_params& dp, int nwork, int per_point, 
             (void)hipFuncSetAttribute((const void*)point_kernel<F, LAYOUT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL((point_kernel<F, LAYOUT>), grid, block, lds, s, dp, nwork, per_point, nr, nsv, svmin, d_tD, d_rD, d_sv, \
                            (const double2*)d_tab, d_h, d_dh, d_stats, nt, ir0, nrc, (double2*)d_totlap, (double2*)d_glscr,          \
-                           (double2*)d_state, (const int*)d_ndone);                                            \
+                           (double2*)d_state, (const int*)d_ndone, (const int*)d_todo);                        \
     } while (0)
     switch (fam) {
     case 0: UCF_LAUNCH(0); break;

@@ -5,6 +5,7 @@
 #define UCF_WAVE 64
 #define UCF_MAX_R 16
 extern int ucf_grid_slots;     /* workgroups per launch (grid-stride over the work items); each owns a scratch slot */
+extern int ucf_finish_part;   /* diagnostic: lanes per scratch part in finish_kernel (16/32/64; 0 = choose from the LDS footprint) */
 #define UCF_GRID_SLOTS ucf_grid_slots
 
 // Everything a kernel needs, passed by value as one kernel argument (lives in
