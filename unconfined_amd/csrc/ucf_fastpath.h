@@ -123,6 +123,7 @@ struct fast_common {
     cplx th, eta, ff1, ff2, inv_she, she, che, top, g3, inv_den, ex1;   // ex1 = exp(-eta)
     cplx fd_s1;          // FD: sigma(1)
     bool small_eta, fd_use;
+    bool any_small, any_large;   // wave-uniform: some lane on the cosh/sinh form, some lane on the exponential form
 };
 
 // theta and eta of this abscissa.  Returns false (for this lane) if the fast evaluation is not applicable:
@@ -153,12 +154,22 @@ UCF_DEV void fast_common_terms(const ucf_dev_params& P, const lane_consts& L, do
 {
     const double a2 = a * a;
     const bool hantush = !(FAMILY == 2 && P.model == 4);
-    const fprim p1 = prim(S.eta.re, S.eta.im);
-    S.che = pcosh(p1);
-    S.she = psinh(p1);
-    S.ex1 = pexpneg(p1);
+    const bool z1 = P.fold_dD != 0, z2 = P.fold_lD1 != 0;
+    // the water-table closure switches to its exponential form at Re(eta) >= maxexp (:84) and then needs neither
+    // cosh(eta) nor sinh(eta): decide per wave what has to be evaluated at all
+    S.small_eta = (FAMILY != 2) || (S.eta.re < P.maxexp);                                       // :84
+    S.any_small = (FAMILY != 2) || (__builtin_amdgcn_ballot_w64(S.small_eta) != 0);
+    S.any_large = (FAMILY == 2) && (__builtin_amdgcn_ballot_w64(!S.small_eta) != 0);
+    const bool need_p1 = (hantush && (!(z1 && z2) || need_lay1)) || FAMILY == 4 || (FAMILY == 2 && S.any_small);
+    if (need_p1) {
+        const fprim p1 = prim(S.eta.re, S.eta.im);
+        S.che = pcosh(p1);
+        S.she = psinh(p1);
+        S.ex1 = pexpneg(p1);
+    } else {
+        S.che = S.she = S.ex1 = cmake(0.0, 0.0);
+    }
     if (hantush) {
-        const bool z1 = P.fold_dD != 0, z2 = P.fold_lD1 != 0;
         fprim pd;
         if (!z1) { pd = prim(S.eta.re * P.dD, S.eta.im * P.dD); S.ff1 = psinh(pd); }           // :176
         else S.ff1 = cmake(0.0, 0.0);
@@ -185,7 +196,6 @@ UCF_DEV void fast_common_terms(const ucf_dev_params& P, const lane_consts& L, do
     }
     if (FAMILY == 2) {
         const cplx xi = cmul(S.eta, L.xifac);                                                   // :70-75
-        S.small_eta = S.eta.re < P.maxexp;                                                      // :84
         cplx one_bex = cmake(1.0, 0.0);
         if (P.beta != 0.0) one_bex = radd(1.0, cmul(rscale(P.beta, S.eta), xi));
         if (S.small_eta) S.inv_den = cinv_auto(cadd(cmul(one_bex, S.che), cmul(xi, S.she)));  // :86-87
@@ -232,7 +242,7 @@ UCF_DEV cplx fast_hantush_z(const ucf_dev_params& P, const fast_common& S, doubl
                             cplx* exz_out)
 {
     const bool z1 = P.fold_dD != 0, z2 = P.fold_lD1 != 0;
-    const bool need_chz = (lay == 1) || !z1 || FAMILY == 2 || FAMILY == 4;
+    const bool need_chz = (lay == 1) || !z1 || (FAMILY == 2 && S.any_small) || FAMILY == 4;
     cplx chz = cmake(1.0, 0.0);
     if (need_chz) chz = pcosh(prim(S.eta.re * zD, S.eta.im * zD));
     *chz_out = chz;
@@ -241,10 +251,10 @@ UCF_DEV cplx fast_hantush_z(const ucf_dev_params& P, const fast_common& S, doubl
         udp = cmul(S.g3, chz);                                                                  // :188
     } else {
         cplx g2 = cmake(0.0, 0.0);
-        const bool need_1z = !z2 || (FAMILY == 2 && !S.small_eta);
+        const bool need_1z = !z2 || (FAMILY == 2 && S.any_large);
         fprim p1z;
         if (need_1z) { const double c = 1.0 - zD; p1z = prim(S.eta.re * c, S.eta.im * c); }
-        if (FAMILY == 2 && !S.small_eta) *exz_out = pexpneg(p1z);                               // exp(eta*(zD-1))
+        if (FAMILY == 2 && S.any_large) *exz_out = pexpneg(p1z);                                // exp(eta*(zD-1))
         if (!(z1 && z2)) {
             cplx num = cmake(0.0, 0.0);
             if (!z1) num = cmul(S.ff1, chz);
@@ -276,11 +286,11 @@ UCF_DEV cplx fast_sample_z(const ucf_dev_params& P, const fast_common& S, int iz
     cplx u;
     if (P.model == 4) {
         u = S.th;
-        if (S.small_eta) chz = pcosh(prim(S.eta.re * zD, S.eta.im * zD));
-        else { const double c = 1.0 - zD; exz = pexpneg(prim(S.eta.re * c, S.eta.im * c)); }
+        if (S.any_small) chz = pcosh(prim(S.eta.re * zD, S.eta.im * zD));
+        if (S.any_large) { const double c = 1.0 - zD; exz = pexpneg(prim(S.eta.re * c, S.eta.im * c)); }
     } else {
         u = fast_hantush_z<2>(P, S, zD, lay, &chz, &exz);
-        if (!S.small_eta && lay == 1) { const double c = 1.0 - zD; exz = pexpneg(prim(S.eta.re * c, S.eta.im * c)); }
+        if (S.any_large && lay == 1) { const double c = 1.0 - zD; exz = pexpneg(prim(S.eta.re * c, S.eta.im * c)); }
     }
     if (S.small_eta) return csub(u, cmul(cmul(S.top, chz), S.inv_den));                         // :85-87
     return csub(u, cmul(cmul(S.top, exz), S.inv_den));                                          // :89-91
