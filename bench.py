@@ -270,6 +270,18 @@ def main():
                 traffic = json.load(open(tpath)).get(args.mode, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        executed = None
+        ppath = os.path.join(ROOT, "profiles", "pmc_r01.json")
+        if os.path.exists(ppath) and wl_name.startswith("C2:") and args.mode == "fast":
+            try:
+                pm = json.load(open(ppath))["fast"]
+                fl = pm.get("fp64_flop_executed_per_launch")
+                if fl:
+                    executed = {"fp64_flop_per_launch": fl, "TFLOPs": fl / (kern_ms * 1e-3) * 1e-12,
+                                "frac_of_peak": fl / (kern_ms * 1e-3) * 1e-12 / PEAK_FP64_VALU_TFLOPS,
+                                "valu_busy": pm.get("valu_busy_per_simd"), "source": "profiles/pmc_r01.json (rocprofv3 --pmc of this workload)"}
+            except Exception:
+                executed = None
         line = {
             "metric": "(t,r) drawdown points/sec, Neuman-1974 1024x256 sweep; max |rel err| vs CPU ref",
             "value": value, "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -284,6 +296,9 @@ def main():
                          "frac": achieved_tf / PEAK_FP64_VALU_TFLOPS, "traffic": traffic,
                          "kernel": dom_name or "all kernels of a step", "kernel_ms": kern_ms,
                          "step_kernels_ms": step_kernels_ms, "flop_per_point": flop_per_pt,
+                         "convention": "SURVEY.md 8(d): 1.42 kflop per Laplace-Hankel sample as the reference formulates it (+0.1 Mflop tail per point); "
+                                       "frac > 1 = the kernel needs fewer flops than that formulation, see `executed` for the instructions it really issues",
+                         "executed": executed,
                          "peak_measured_fp64_fma": fma_peak,
                          "frac_of_measured_fma": (achieved_tf / fma_peak) if fma_peak else None,
                          "hbm": {"algorithmic_bytes_per_launch": alg_bytes,
