@@ -992,44 +992,58 @@ integrate_kernel(const ucf_dev_params P, int npts, int per_point, int nr, int ns
         double2* __restrict__ sti = state + (size_t)pt * state_slots(P) * UCF_WAVE;
         double2* __restrict__ areas = sti + (size_t)(R + 1) * nz * UCF_WAVE;
         for (int s = 0; s < (R + 1) * nz; s++) lds_st(lds, s, lane, cmake(0.0, 0.0));
+        fast_common F;
 
         // abscissae increase monotonically (tanh-sinh on [0,arg], then the J0 intervals), so does Re(eta):
-        // the fast evaluation is valid for a leading run of abscissae; point_kernel finishes the rest
+        // the fast evaluation is valid for a leading run of abscissae; point_kernel finishes the rest.
+        // The row entry of the next abscissa is requested one iteration ahead (scalar loads).
         int n = 0;
-        for (; n < nabs; n++) {
-            const double2 aa = row[n];
-            fast_common F;
+        double2 aa = row[0];
+        int m = 0, jj = 0;                        // Gauss-Lobatto node and J0 interval of abscissa n >= N
+        cplx acc0 = cmake(0.0, 0.0);              // running area of the interval: a register when nz = 1,
+        for (; n < nabs; n++) {                   // else accCur[z] in LDS
+            const double2 nxt = row[n + 1 < nabs ? n + 1 : n];
+            const bool ts = n < N;
+            const double w = ts ? 0.0 : P.gl_w[m];
             if (!__all(fast_eta<FAMILY>(P, LC, aa.x, F))) break;
             fast_common_terms<FAMILY>(P, LC, aa.x, need_lay1, F);
+            const int n1 = n + 1;
+            int tz = __builtin_ctz(n1);
+            if (tz > R - 1) tz = R - 1;
             for (int z = 0; z < nz; z++) {
                 // val = a*J0(a rD) * f(a,p,z) * lapTime(p)                                      (lhs.f90:118)
                 const cplx val = cmul(rscale(aa.y, fast_sample_z<FAMILY>(P, F, z)), lt);
-                if (n < N) {
-                    // abscissa n+1 belongs to level j when 2^(R-j) divides it                  (driver.f90:150)
-                    const int n1 = n + 1;
-                    int tz = __builtin_ctz(n1);
-                    if (tz > R - 1) tz = R - 1;
+                if (ts) {
+                    // tanh-sinh on [0, arg]: abscissa n+1 belongs to level j when 2^(R-j) divides it  (driver.f90:129-157)
                     for (int sh = 0; sh <= tz; sh++) {
                         const int j = R - sh;
-                        const double w = P.ts_w[(size_t)(j - 1) * N + ((n1 >> sh) - 1)];
+                        const double wl = P.ts_w[(size_t)(j - 1) * N + ((n1 >> sh) - 1)];
                         const int slot = (j - 1) * nz + z;
-                        lds_st(accTS, slot, lane, cadd(lds_ld(accTS, slot, lane), rscale(w, val)));
+                        lds_st(accTS, slot, lane, cadd(lds_ld(accTS, slot, lane), rscale(wl, val)));
                     }
+                } else if (nz == 1) {
+                    acc0 = cadd(acc0, cscale(val, w));                                          // :201-202
                 } else {
-                    const int g = n - N;
-                    const int jj = g / ngl, m = g - jj * ngl;
-                    cplx acc = cadd(lds_ld(accCur, z, lane), cscale(val, P.gl_w[m]));           // :201-202
-                    if (m == ngl - 1) {
-                        const double lob = P.j0z[sv + jj - 1] / rD;
-                        const double hib = P.j0z[sv + jj] / rD;
-                        acc = rscale((hib - lob) / 2.0, acc);
-                        areas[(size_t)(jj * nz + z) * UCF_WAVE + lane] = make_double2(acc.re, acc.im);
-                        acc = cmake(0.0, 0.0);
-                    }
-                    lds_st(accCur, z, lane, acc);
+                    lds_st(accCur, z, lane, cadd(lds_ld(accCur, z, lane), cscale(val, w)));
                 }
             }
+            if (!ts && ++m == ngl) {
+                // Gauss-Lobatto between successive J0 zeros: the interval is complete           (driver.f90:187-203)
+                const double lob = P.j0z[sv + jj - 1] / rD;
+                const double hib = P.j0z[sv + jj] / rD;
+                const double hw = (hib - lob) / 2.0;
+                for (int z = 0; z < nz; z++) {
+                    const cplx ar = rscale(hw, nz == 1 ? acc0 : lds_ld(accCur, z, lane));
+                    areas[(size_t)(jj * nz + z) * UCF_WAVE + lane] = make_double2(ar.re, ar.im);
+                    if (nz != 1) lds_st(accCur, z, lane, cmake(0.0, 0.0));
+                }
+                acc0 = cmake(0.0, 0.0);
+                m = 0;
+                jj++;
+            }
+            aa = nxt;
         }
+        if (nz == 1) lds_st(accCur, 0, lane, acc0);       // an unfinished interval travels with the state
         for (int s = 0; s < (R + 1) * nz; s++) sti[(size_t)s * UCF_WAVE + lane] = lds[s * UCF_WAVE + lane];
         if (lane == 0) {
             ndone[pt] = n;
