@@ -957,11 +957,9 @@ point_kernel(const ucf_dev_params P, int npts, int per_point, int nr, int nsv, i
 // The level sums, the running interval area and the finished interval areas go to the item's state
 // (HBM, written once, coalesced 1 KB per slot); point_kernel resumes from there: remaining abscissae
 // with the generic evaluator (the overflow regime the fast one leaves alone), Richardson, Wynn, de Hoog.
-#ifndef UCF_INTEGRATE_WAVES
-#define UCF_INTEGRATE_WAVES 4
-#endif
-template <int FAMILY, int LAYOUT>
-__global__ void __launch_bounds__(UCF_WAVE, UCF_INTEGRATE_WAVES)
+// WAVES per SIMD the register budget is cut for: 5 when the LDS footprint lets 20 waves share a CU (nz = 1), else 4
+template <int FAMILY, int LAYOUT, int WAVES>
+__global__ void __launch_bounds__(UCF_WAVE, WAVES)
 integrate_kernel(const ucf_dev_params P, int npts, int per_point, int nr, int nsv, int svmin,
                  const double* __restrict__ tDv, const double* __restrict__ rDv, const int* __restrict__ svv,
                  const double2* __restrict__ tab, int nt, int ir0, double2* __restrict__ state, int* __restrict__ ndone,
@@ -1397,17 +1395,18 @@ static int launch_transform(const ucf_dev_params& dp, int nwork, int per_point, 
         const size_t ilds = (size_t)(dp.R + 1) * dp.nz * UCF_WAVE * sizeof(lds_c);
         (void)hipMemsetAsync(d_todo, 0, sizeof(int), s);
         if (ev0) (void)hipEventRecord((hipEvent_t)ev0, s);
-#define UCF_LAUNCH_I(F)                                                                                        \
+#define UCF_LAUNCH_I(F, W)                                                                                     \
     do {                                                                                                       \
         if (ilds > 64 * 1024)                                                                                  \
-            (void)hipFuncSetAttribute((const void*)integrate_kernel<F, LAYOUT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ilds); \
-        hipLaunchKernelGGL((integrate_kernel<F, LAYOUT>), dim3((unsigned)nwork), block, ilds, s, dp, nwork, per_point, nr, nsv, svmin, \
+            (void)hipFuncSetAttribute((const void*)integrate_kernel<F, LAYOUT, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ilds); \
+        hipLaunchKernelGGL((integrate_kernel<F, LAYOUT, W>), dim3((unsigned)nwork), block, ilds, s, dp, nwork, per_point, nr, nsv, svmin, \
                            d_tD, d_rD, d_sv, (const double2*)d_tab, nt, ir0, (double2*)d_state, d_ndone, d_todo); \
     } while (0)
+        const bool w5 = ilds * 20 <= 160 * 1024;
         switch (fam) {
-        case 1: UCF_LAUNCH_I(1); break;
-        case 2: UCF_LAUNCH_I(2); break;
-        case 4: UCF_LAUNCH_I(4); break;
+        case 1: UCF_LAUNCH_I(1, 4); break;
+        case 2: if (w5) UCF_LAUNCH_I(2, 5); else UCF_LAUNCH_I(2, 4); break;
+        case 4: UCF_LAUNCH_I(4, 4); break;
         }
 #undef UCF_LAUNCH_I
         if (ev1) (void)hipEventRecord((hipEvent_t)ev1, s);
