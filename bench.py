@@ -267,7 +267,10 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
         if os.path.exists(tpath):
             try:
+                # measured on the full 1024 x 256 C2 sweep; traffic is proportional to the points of a launch
                 traffic = json.load(open(tpath)).get(args.mode, {}).get("hbm_bytes_per_launch")
+                if traffic is not None:
+                    traffic = traffic * (npts / 262144.0) if wl_name.startswith("C2:") else None
             except Exception:
                 traffic = None
         executed = None
@@ -277,6 +280,7 @@ def main():
                 pm = json.load(open(ppath))["fast"]
                 fl = pm.get("fp64_flop_executed_per_launch")
                 if fl:
+                    fl = fl * (npts / 262144.0)          # counted on the full 1024 x 256 sweep
                     executed = {"fp64_flop_per_launch": fl, "TFLOPs": fl / (kern_ms * 1e-3) * 1e-12,
                                 "frac_of_peak": fl / (kern_ms * 1e-3) * 1e-12 / PEAK_FP64_VALU_TFLOPS,
                                 "valu_busy": pm.get("valu_busy_per_simd"), "source": "profiles/pmc_r01.json (rocprofv3 --pmc of this workload)"}
