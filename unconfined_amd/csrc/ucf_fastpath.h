@@ -55,11 +55,12 @@ UCF_DEV fprim prim(double x, double y)
     double s;
     if (ax < 0.35) {
         const double x2 = ax * ax;
-        double pl = addk(mulk(x2, 1.0 / 6227020800.0), 1.0 / 39916800.0);
-        pl = fmak(pl, x2, 1.0 / 362880.0);
-        pl = fmak(pl, x2, 1.0 / 5040.0);
-        pl = fmak(pl, x2, 1.0 / 120.0);
-        pl = fmak(pl, x2, 1.0 / 6.0);
+        const int salt = __builtin_amdgcn_readfirstlane(__double2hiint(x));
+        double pl = addk(mulk(x2, UCF_KHERE(1.0 / 6227020800.0, salt)), UCF_KHERE(1.0 / 39916800.0, salt));
+        pl = fmak(pl, x2, UCF_KHERE(1.0 / 362880.0, salt));
+        pl = fmak(pl, x2, UCF_KHERE(1.0 / 5040.0, salt));
+        pl = fmak(pl, x2, UCF_KHERE(1.0 / 120.0, salt));
+        pl = fmak(pl, x2, UCF_KHERE(1.0 / 6.0, salt));
         s = __builtin_fma(ax * x2, pl, ax);
     } else {
         s = 0.5 * (e - ei);

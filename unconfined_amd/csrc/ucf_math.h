@@ -119,6 +119,23 @@ UCF_DEV double addk(double a, double c)
     asm("v_add_f64 %0, %1, %2" : "=v"(o) : "v"(a), "s"(c));
     return o;
 }
+// A 64-bit constant materialised (two s_mov_b32) where it is used.  The compiler hoists loop-invariant
+// constants into SGPRs for the whole abscissa loop; ~45 coefficient pairs do not fit beside the loop's own
+// invariants, and what does not fit is parked in VGPR lanes and fetched back with v_readlane_b32 -- VALU work
+// again.  `salt` is any wave-uniform value that changes per iteration: it only pins the s_mov to its place.
+template <unsigned long long BITS>
+UCF_DEV double sgpr_const_here(int salt)
+{
+    unsigned lo, hi;
+    asm("s_mov_b32 %0, %1 ; constant kept local (%2)" : "=s"(lo) : "n"((unsigned)(BITS & 0xffffffffull)), "s"(salt));
+    asm("s_mov_b32 %0, %1 ; constant kept local (%2)" : "=s"(hi) : "n"((unsigned)(BITS >> 32)), "s"(salt));
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+#ifdef UCF_NO_LOCAL_CONSTANTS
+#define UCF_KHERE(c, salt) (c)
+#else
+#define UCF_KHERE(c, salt) sgpr_const_here<__builtin_bit_cast(unsigned long long, (double)(c))>(salt)
+#endif
 // g = sqrt(x) and h = 1/(2 sqrt(x)) together, 1e-290 < x < 1e290 (no scaling): v_rsq_f64 estimate and two
 // coupled Newton steps on (g, h), then one correction of g.  g < 1 ulp, h ~ 1 ulp.
 UCF_DEV void sqrt_hrsqrt(double x, double* g_out, double* h_out)
@@ -188,26 +205,27 @@ __device__ __noinline__ static double2 sincos_huge_(double y) { double s, c; sin
 // |x| < 1e6 (the caller's business)
 UCF_DEV void sincos_medium_(double x, double* sn, double* cs)
 {
-    const double fn = __builtin_rint(x * 6.36619772367581382433e-01);
+    const int salt = __builtin_amdgcn_readfirstlane(__double2hiint(x));
+#define K(c) UCF_KHERE(c, salt)
+    const double fn = __builtin_rint(mulk(x, K(6.36619772367581382433e-01)));
     double r = __builtin_fma(-fn, 1.57079632673412561417e+00, x);          // exact (33-bit constant)
     const double t = r;
-    double w = fn * 6.07710050630396597660e-11;                            // pio2_2
+    double w = mulk(fn, K(6.07710050630396597660e-11));                    // pio2_2
     r = t - w;
     w = __builtin_fma(fn, 2.02226624879595063154e-21, -((t - r) - w));     // pio2_2t
     const double y0 = r - w;
     const double y1 = (r - y0) - w;
     const double z = y0 * y0;
     // __kernel_sin(y0, y1, 1)
-    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
-                 S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
     const double v = z * y0;
-    const double rs = fmak(z, fmak(z, fmak(z, addk(mulk(z, S6), S5), S4), S3), S2);
-    const double ksin = y0 - ((z * (0.5 * y1 - v * rs) - y1) - v * S1);
+    const double rs = fmak(z, fmak(z, fmak(z, addk(mulk(z, K(1.58969099521155010221e-10)), K(-2.50507602534068634195e-08)),
+                                           K(2.75573137070700676789e-06)), K(-1.98412698298579493134e-04)), K(8.33333333332248946124e-03));
+    const double ksin = y0 - ((z * (0.5 * y1 - v * rs) - y1) - mulk(v, K(-1.66666666666666324348e-01)));
     // __kernel_cos(y0, y1)  (msun form, branch free)
-    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
-                 C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
     const double ww = z * z;
-    const double rc = __builtin_fma(ww * ww, fmak(z, addk(mulk(z, C6), C5), C4), z * fmak(z, addk(mulk(z, C3), C2), C1));
+    const double rc = __builtin_fma(ww * ww, fmak(z, addk(mulk(z, K(-1.13596475577881948265e-11)), K(2.08757232129817482790e-09)), K(-2.75573143513906633035e-07)),
+                                    z * fmak(z, addk(mulk(z, K(2.48015872894767294178e-05)), K(-1.38888888888741095749e-03)), K(4.16666666666666019037e-02)));
+#undef K
     const double hz = 0.5 * z;
     const double w1 = 1.0 - hz;
     const double kcos = w1 + (((1.0 - w1) - hz) + (z * rc - y0 * y1));
