@@ -25,7 +25,16 @@ using namespace ucfm;
 
 // ------------------------------------------------------------------ wave helpers
 UCF_DEV double shfl_down1(double v) { return __shfl_down(v, 1, 64); }
-UCF_DEV cplx shfl_down1(cplx v) { return cmake(__shfl_down(v.re, 1, 64), __shfl_down(v.im, 1, 64)); }
+// lane i <- lane i+1 (lane 63 keeps its own value, like __shfl_down): one DPP move per dword
+// (wave_shl:1) instead of a ds_bpermute round trip through the LDS crossbar
+UCF_DEV double shift_down1(double x)
+{
+    const int lo = __double2loint(x), hi = __double2hiint(x);
+    const int l2 = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false);
+    const int h2 = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
+    return __hiloint2double(h2, l2);
+}
+UCF_DEV cplx shfl_down1(cplx v) { return cmake(shift_down1(v.re), shift_down1(v.im)); }
 UCF_DEV cplx bcast0(cplx v) { return cmake(__shfl(v.re, 0, 64), __shfl(v.im, 0, 64)); }
 UCF_DEV double wave_max(double v)
 {

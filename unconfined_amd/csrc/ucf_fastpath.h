@@ -25,19 +25,26 @@ struct fprim {
 // (|r| <= 0.3466: truncation 4e-18), scaled by 2^k.
 UCF_DEV double exp_pos(double x)
 {
-    const double k = __builtin_rint(x * 1.4426950408889634074);
+#ifdef UCF_EXP_LOCAL_CONSTANTS
+    const int salt = __builtin_amdgcn_readfirstlane(__double2hiint(x));
+#define K(c) UCF_KHERE(c, salt)
+#else
+#define K(c) (c)
+#endif
+    const double k = __builtin_rint(mulk(x, K(1.4426950408889634074)));
     double r = __builtin_fma(-k, 6.93147180369123816490e-01, x);
     r = __builtin_fma(-k, 1.90821492927058770002e-10, r);
-    double q = addk(mulk(r, 1.0 / 6227020800.0), 1.0 / 479001600.0);
-    q = fmak(q, r, 1.0 / 39916800.0);
-    q = fmak(q, r, 1.0 / 3628800.0);
-    q = fmak(q, r, 1.0 / 362880.0);
-    q = fmak(q, r, 1.0 / 40320.0);
-    q = fmak(q, r, 1.0 / 5040.0);
-    q = fmak(q, r, 1.0 / 720.0);
-    q = fmak(q, r, 1.0 / 120.0);
-    q = fmak(q, r, 1.0 / 24.0);
-    q = fmak(q, r, 1.0 / 6.0);
+    double q = addk(mulk(r, K(1.0 / 6227020800.0)), K(1.0 / 479001600.0));
+    q = fmak(q, r, K(1.0 / 39916800.0));
+    q = fmak(q, r, K(1.0 / 3628800.0));
+    q = fmak(q, r, K(1.0 / 362880.0));
+    q = fmak(q, r, K(1.0 / 40320.0));
+    q = fmak(q, r, K(1.0 / 5040.0));
+    q = fmak(q, r, K(1.0 / 720.0));
+    q = fmak(q, r, K(1.0 / 120.0));
+    q = fmak(q, r, K(1.0 / 24.0));
+    q = fmak(q, r, K(1.0 / 6.0));
+#undef K
     q = __builtin_fma(q, r, 0.5);
     q = __builtin_fma(q, r, 1.0);
     q = __builtin_fma(q, r, 1.0);
