@@ -384,6 +384,49 @@ def test_edge_cases(engine, oracle, oracle_quad):
         assert np.array_equal(hg[:, 0, :], h), M            # grid (lane = time) and per-point entries: same bits
 
 
+_PIPE_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+from golden_util import load_deck
+from unconfined_amd import engine
+out = {}
+for name in ("c2_neuman74_fullpen", "neuman74_partpen"):
+    dk, ts, P = load_deck(name)
+    plan = engine.Plan(P, mode="fast")
+    zD = np.array([0.3, 0.91]); zl = plan.zlay(zD)
+    tD = 10.0 ** np.linspace(-2, 4, 150); sv = plan.split_vector(tD)
+    rD = np.array([0.02, 0.1, 0.7, 3.0, 9.0])          # 0.02: overflow regime -> unfinished items -> point_kernel
+    h, dh = plan.drawdown_grid(tD, sv, rD, zD, zl)
+    TT, RR = np.meshgrid(tD[::7], rD, indexing="ij")
+    hb, dhb = plan.drawdown(TT.ravel(), RR.ravel(), np.repeat(sv[::7], len(rD)), zD, zl)
+    out[name + "_h"], out[name + "_dh"], out[name + "_hb"], out[name + "_dhb"] = h, dh, hb, dhb
+np.savez(sys.argv[2], **out)
+"""
+
+
+def test_pipeline_knobs_do_not_change_results(tmp_path):
+    """the fast flavour's kernel pipeline (integrate -> finish -> resume of unfinished items): cutting the work
+    into small state-budget chunks and every scratch-part width of finish_kernel give the same bits"""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for tag, env in (("default", {}), ("chunks", {"UCF_STATE_BYTES": str(3 << 20)}), ("part16", {"UCF_FINISH_PART": "16"}),
+                     ("part32", {"UCF_FINISH_PART": "32"})):
+        out = str(tmp_path / f"{tag}.npz")
+        e = dict(os.environ); e.update(env)
+        subprocess.run([sys.executable, "-c", _PIPE_SCRIPT, root, out], check=True, env=e, timeout=600)
+        res[tag] = np.load(out)
+    ref = res["default"]
+    for tag in ("chunks", "part16", "part32"):
+        for k in ref.files:
+            assert np.array_equal(ref[k], res[tag][k], equal_nan=True), (tag, k)
+    # grid (lane = time) and batch (lane = Laplace sample) agree to rounding of the fast flavour's contractions
+    for name in ("c2_neuman74_fullpen", "neuman74_partpen"):
+        hg = ref[name + "_h"][::7]; hb = ref[name + "_hb"].reshape(hg.shape)
+        assert np.array_equal(np.isnan(hg), np.isnan(hb))
+        assert rel_err(hg[:, 1:], hb[:, 1:], 1e-6).max() < 1e-6, name      # (column 0 is the overflow regime)
+
+
 def test_parameter_batched_sweep(engine):
     """f4: the same observation points under 12 parameter sets in one call == 12 single-plan calls"""
     from unconfined_amd.abi import params_from_deck
