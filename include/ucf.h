@@ -176,8 +176,11 @@ int ucf_drawdown_grid_device(ucf_plan* plan, int nt, const double* d_tD, const i
 /* Parameter-batched evaluation for inversion / fitting (the tool's real use,
  * reference README.md:45-56): the SAME observation points -- dimensional times t[npts], radii r[npts],
  * depths z[nz] (z up from the aquifer base) -- under nplans parameter sets.  Each plan
- * non-dimensionalises with its own Lc, Tc (driver_io.f90:531-567), gets its own layers and split vector,
- * and runs on one of a small pool of HIP streams so that the small launches overlap.
+ * non-dimensionalises with its own Lc, Tc (driver_io.f90:531-567), gets its own layers and split vector.
+ * Fast-flavour plans of the same model and numerical settings (M, k/R, nacc/ord, alpha, tol, J0 split) -- the
+ * fitting case: only hydraulic / geometric parameters vary -- share ONE launch sequence over (plan, point) work
+ * items with per-plan parameter blocks in device memory; any other mix runs plan by plan on a small pool of
+ * HIP streams so that the small launches overlap.  Either way the results equal the single-plan calls bit for bit.
  * h, dh: [nplans][npts][nz]; dimensional (x Hc of each plan) unless dimensionless != 0. */
 int ucf_drawdown_multi(ucf_plan* const* plans, int nplans, int npts, const double* t, const double* r,
                        int nz, const double* z, int dimensionless, double* h, double* dh);

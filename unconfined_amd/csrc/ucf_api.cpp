@@ -598,7 +598,7 @@ size_t state_budget()
 
 int launch_points_any(ucf_plan* pl, const ucf_dev_params& dp, int npts, int per_point, int nr, int nsv, int svmin,
                       const double* d_tD, const double* d_rD, const int* d_sv, double* d_h, double* d_dh,
-                      ucf_stats* d_stats, void* stream)
+                      ucf_stats* d_stats, void* stream, const ucf_dev_params* d_params = nullptr, int ppp = 1)
 {
     int rc = ensure_glscr(pl, dp.nz);
     if (rc) return rc;
@@ -636,11 +636,11 @@ int launch_points_any(ucf_plan* pl, const ucf_dev_params& dp, int npts, int per_
         double* dh = d_dh + base * dp.nz_out;
         if (chunked) {
             rc = (pl->mode == 1)
-                     ? ucf_fast::launch_points_chunked(dp, n, per_point, nr, nsv, svmin, tD, rD, sv, tab, pl->d_totlap, h, dh, d_stats, stream, pl->d_glscr, pl->d_state, pl->d_ndone)
+                     ? ucf_fast::launch_points_chunked(dp, n, per_point, nr, nsv, svmin, tD, rD, sv, tab, pl->d_totlap, h, dh, d_stats, stream, pl->d_glscr, pl->d_state, pl->d_ndone, d_params, ppp, (int)base)
                      : ucf_faithful::launch_points_chunked(dp, n, per_point, nr, nsv, svmin, tD, rD, sv, tab, pl->d_totlap, h, dh, d_stats, stream, pl->d_glscr, nullptr, nullptr);
         } else {
             rc = (pl->mode == 1)
-                     ? ucf_fast::launch_points(dp, n, per_point, nr, nsv, svmin, tD, rD, sv, tab, h, dh, d_stats, stream, pl->d_glscr, pl->d_state, pl->d_ndone)
+                     ? ucf_fast::launch_points(dp, n, per_point, nr, nsv, svmin, tD, rD, sv, tab, h, dh, d_stats, stream, pl->d_glscr, pl->d_state, pl->d_ndone, d_params, ppp, (int)base)
                      : ucf_faithful::launch_points(dp, n, per_point, nr, nsv, svmin, tD, rD, sv, tab, h, dh, d_stats, stream, pl->d_glscr, nullptr, nullptr);
         }
         if (rc == UCF_ERR_UNSUPPORTED) return fail(rc, "this model / size combination has no kernel (model %d, LDS limit)", dp.model);
@@ -882,6 +882,22 @@ int ucf_drawdown_multi(ucf_plan* const* plans, int nplans, int npts, const doubl
         rc = check_sv(plans[k], npts, &sv[k * np_]);
         if (rc) return rc;
     }
+    // Plans that differ only in what the evaluators read (hydraulic / geometric parameters) share one launch
+    // sequence: work item = (plan, point), parameter block per plan in device memory.  Anything that shapes the
+    // work must agree; otherwise every plan gets its own launches on a pool of streams.
+    bool one_launch = (nplans > 1) && (tot <= 0x7fffffffULL);
+    for (int k = 0; k < nplans && one_launch; k++) {
+        const ucf_plan* a = plans[0];
+        const ucf_plan* b = plans[k];
+        const ucf_dev_params &x = a->dev, &y = b->dev;
+        one_launch = a->mode == 1 && b->mode == 1 && a->device == b->device && a->force_layout0 == b->force_layout0 &&
+                     (x.model == 1 || x.model == 3 || x.model == 4 || x.model == 5 || (x.model == 6 && x.MNtype == 2)) &&   // integrate_kernel models
+                     x.model == y.model && x.MNtype == y.MNtype && x.order == y.order && x.MoenchM == y.MoenchM &&
+                     x.M == y.M && x.k == y.k && x.R == y.R && x.nacc == y.nacc && x.ngl == y.ngl && x.N == y.N &&
+                     x.nj0z == y.nj0z && x.alpha == y.alpha && x.logtol == y.logtol &&
+                     a->P.j0s[0] == b->P.j0s[0] && a->P.j0s[1] == b->P.j0s[1] && (x.timeType >= 0) == (y.timeType >= 0) &&
+                     (x.timeType >= 0 || x.timeType == y.timeType);
+    }
     dev_buf b_t, b_r, b_s, b_h, b_d;
     if (b_t.alloc(sizeof(double) * tot) || b_r.alloc(sizeof(double) * tot) || b_s.alloc(sizeof(int) * tot) ||
         b_h.alloc(sizeof(double) * tot * nz) || b_d.alloc(sizeof(double) * tot * nz))
@@ -889,6 +905,44 @@ int ucf_drawdown_multi(ucf_plan* const* plans, int nplans, int npts, const doubl
     HIP_TRY(hipMemcpy(b_t.p, tD.data(), sizeof(double) * tot, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(b_r.p, rD.data(), sizeof(double) * tot, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(b_s.p, sv.data(), sizeof(int) * tot, hipMemcpyHostToDevice));
+    if (one_launch) {
+        ucf_plan* pl = plans[0];
+        std::vector<ucf_dev_params> dps(nplans);
+        for (int k = 0; k < nplans; k++) {
+            int rc = fill_call_params(plans[k], nz, &zD[(size_t)k * nz], &zl[(size_t)k * nz], dps[k]);
+            if (rc) return rc;
+        }
+        dev_buf b_p;
+        if (b_p.alloc(sizeof(ucf_dev_params) * nplans)) return fail(UCF_ERR_NOMEM, "device allocation failed for %d parameter blocks", nplans);
+        HIP_TRY(hipMemcpy(b_p.p, dps.data(), sizeof(ucf_dev_params) * nplans, hipMemcpyHostToDevice));
+        // one abscissa row per (plan, point), in chunks that keep the table <= 256 MiB
+        const size_t row_bytes = (size_t)pl->D.nabs * 2 * sizeof(double);
+        size_t chunk = ((size_t)256 << 20) / row_bytes;
+        if (chunk < 1) chunk = 1;
+        if (chunk > tot) chunk = tot;
+        int rc = ensure_work(pl, chunk * row_bytes);
+        if (rc) return rc;
+        for (size_t base = 0; base < tot && rc == UCF_OK; base += chunk) {
+            const int n = (int)((tot - base < chunk) ? tot - base : chunk);
+            rc = ucf_faithful::launch_abscissae(dps[0], n, 1, 1, 0, (const double*)b_r.p + base, (const int*)b_s.p + base, pl->d_work, nullptr);
+            if (rc) return fail(rc, "abscissa kernel launch failed");
+            // points [base, base + n) of the flattened (plan, point) index; plan of point q = q / npts
+            rc = launch_points_any(pl, dps[0], n, 1, 1, 1, 0, (const double*)b_t.p + base, (const double*)b_r.p + base,
+                                   (const int*)b_s.p + base, (double*)b_h.p + base * nz, (double*)b_d.p + base * nz, nullptr, nullptr,
+                                   (const ucf_dev_params*)b_p.p + 0, npts);
+            if (rc) return rc;
+            if (base + chunk < tot) HIP_TRY(hipDeviceSynchronize());      // the next chunk rewrites the table
+        }
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(h, b_h.p, sizeof(double) * tot * nz, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(dh, b_d.p, sizeof(double) * tot * nz, hipMemcpyDeviceToHost));
+        if (!dimensionless)
+            for (int k = 0; k < nplans; k++) {
+                const double Hc = plans[k]->D.Hc;
+                for (size_t i = 0; i < np_ * nz; i++) { h[k * np_ * nz + i] *= Hc; dh[k * np_ * nz + i] *= Hc; }
+            }
+        return UCF_OK;
+    }
     const int NS = 8;
     hipStream_t streams[NS];
     int ns = 0;

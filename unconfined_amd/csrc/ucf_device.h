@@ -856,22 +856,34 @@ UCF_DEV void finish_item(const ucf_dev_params& P, lds_c* accTS, lds_c* scr, cons
     }
 }
 
+// Parameter block of a work item: the launch's own (kernel argument), or -- parameter-batched launches, MULTI --
+// entry pidx / ppp of a device array: every plan of the batch owns ppp consecutive points.  The plans of such a
+// launch share everything that shapes the work (model family, M, k, R, nacc, ord, alpha, tol, depths count), so
+// the kernel-argument block P0 (plan 0) still sizes LDS, loops and tables; only the evaluators read Pv.
+template <bool MULTI>
+UCF_DEV const ucf_dev_params& item_params(const ucf_dev_params& P0, const ucf_dev_params* __restrict__ Pv, int pidx, int ppp)
+{
+    if constexpr (MULTI) return Pv[pidx / ppp];
+    else return P0;
+}
+
 // State handed from integrate_kernel to point_kernel (fast flavour): per work item
 // [(R + 1 + nacc) * nz][64] complex = level sums | area of the interval in progress | finished areas,
 // plus the number of abscissae already integrated.
 UCF_DEV size_t state_slots(const ucf_dev_params& P) { return (size_t)(P.R + 1 + P.nacc) * P.nz; }
 
-template <int FAMILY, int LAYOUT>
+template <int FAMILY, int LAYOUT, bool MULTI>
 __global__ void __launch_bounds__(UCF_WAVE, 2)
-point_kernel(const ucf_dev_params P, int npts, int per_point, int nr, int nsv, int svmin,
+point_kernel(const ucf_dev_params P0, int npts, int per_point, int nr, int nsv, int svmin,
              const double* __restrict__ tDv, const double* __restrict__ rDv, const int* __restrict__ svv,
              const double2* __restrict__ tab, double* __restrict__ hout, double* __restrict__ dhout, ucf_stats* st,
              int nt, int ir0, int nrc, double2* __restrict__ totlap, double2* __restrict__ glscr,
-             double2* __restrict__ state, const int* __restrict__ ndone, const int* __restrict__ todo)
+             double2* __restrict__ state, const int* __restrict__ ndone, const int* __restrict__ todo,
+             const ucf_dev_params* __restrict__ Pv, int ppp, int pbase)
 {
     extern __shared__ lds_c lds[];
     const int lane = threadIdx.x;
-    const int nz = P.nz, R = P.R, nacc = P.nacc, N = P.N, ngl = P.ngl;
+    const int nz = P0.nz, R = P0.R, nacc = P0.nacc, N = P0.N, ngl = P0.ngl;
     const int nabs = N + nacc * ngl;
     lds_c* accTS = lds;                                     // [R][nz]  level sums
     lds_c* accCur = lds + (size_t)R * nz * UCF_WAVE;        // [nz]     area of the J0 interval being integrated
@@ -887,13 +899,13 @@ point_kernel(const ucf_dev_params P, int npts, int per_point, int nr, int nsv, i
     lds_c* fdbuf = accGL + (areas_lds ? (size_t)nacc * nz * UCF_WAVE : 0);
     double2* __restrict__ areas = areas_lds ? nullptr : glscr + (size_t)blockIdx.x * nacc * nz * UCF_WAVE;
 
-    bool need_lay1 = false;
-    for (int z = 0; z < nz; z++) need_lay1 |= (P.zLay[z] == 1);
-
     for (int wi = blockIdx.x; wi < nloop; wi += gridDim.x) {
         const int pt = resume ? todo[1 + wi] : wi;
-        const work_item W = decode_item<LAYOUT>(P, pt, lane, per_point, nr, nt, ir0);
+        const work_item W = decode_item<LAYOUT>(P0, pt, lane, per_point, nr, nt, ir0);
         const int it = W.it, ir = W.ir, mlap = W.mlap, pidx = W.pidx;
+        const ucf_dev_params& P = item_params<MULTI>(P0, Pv, pidx + pbase, ppp);
+        bool need_lay1 = false;
+        for (int z = 0; z < nz; z++) need_lay1 |= (P.zLay[z] == 1);
         const double tD = tDv[it], rD = rDv[ir];
         const int sv = (LAYOUT == 1) ? svmin : svv[it];
         const double2* __restrict__ row = tab + (size_t)(per_point ? pidx : (ir * nsv + (sv - svmin))) * nabs;
@@ -906,7 +918,7 @@ point_kernel(const ucf_dev_params P, int npts, int per_point, int nr, int nsv, i
 
         int n = 0;
         if (resume) {
-            double2* __restrict__ sti = state + (size_t)pt * state_slots(P) * UCF_WAVE;
+            double2* __restrict__ sti = state + (size_t)pt * state_slots(P0) * UCF_WAVE;
             for (int s = 0; s < (R + 1) * nz; s++) lds[s * UCF_WAVE + lane] = sti[(size_t)s * UCF_WAVE + lane];
             areas = sti + (size_t)(R + 1) * nz * UCF_WAVE;
             n = ndone[pt];
@@ -967,27 +979,28 @@ point_kernel(const ucf_dev_params P, int npts, int per_point, int nr, int nsv, i
 // (HBM, written once, coalesced 1 KB per slot); point_kernel resumes from there: remaining abscissae
 // with the generic evaluator (the overflow regime the fast one leaves alone), Richardson, Wynn, de Hoog.
 // WAVES per SIMD the register budget is cut for: 5 when the LDS footprint lets 20 waves share a CU (nz = 1), else 4
-template <int FAMILY, int LAYOUT, int WAVES>
+template <int FAMILY, int LAYOUT, int WAVES, bool MULTI>
 __global__ void __launch_bounds__(UCF_WAVE, WAVES)
-integrate_kernel(const ucf_dev_params P, int npts, int per_point, int nr, int nsv, int svmin,
+integrate_kernel(const ucf_dev_params P0, int npts, int per_point, int nr, int nsv, int svmin,
                  const double* __restrict__ tDv, const double* __restrict__ rDv, const int* __restrict__ svv,
                  const double2* __restrict__ tab, int nt, int ir0, double2* __restrict__ state, int* __restrict__ ndone,
-                 int* __restrict__ todo)
+                 int* __restrict__ todo, const ucf_dev_params* __restrict__ Pv, int ppp, int pbase)
 {
     extern __shared__ lds_c lds[];
 #ifdef UCF_K1_ASSUME
+    const ucf_dev_params& P = P0;
     UCF_K1_ASSUME      // tools/: specialise a probe build to one plan shape to read its inner loop
 #endif
     const int lane = threadIdx.x;
-    const int nz = P.nz, R = P.R, nacc = P.nacc, N = P.N, ngl = P.ngl;
+    const int nz = P0.nz, R = P0.R, nacc = P0.nacc, N = P0.N, ngl = P0.ngl;
     const int nabs = N + nacc * ngl;
     lds_c* accTS = lds;                                     // [R][nz]  level sums
     lds_c* accCur = lds + (size_t)R * nz * UCF_WAVE;        // [nz]     area of the J0 interval being integrated
-    bool need_lay1 = false;
-    for (int z = 0; z < nz; z++) need_lay1 |= (P.zLay[z] == 1);
-
     for (int pt = blockIdx.x; pt < npts; pt += gridDim.x) {
-        const work_item W = decode_item<LAYOUT>(P, pt, lane, per_point, nr, nt, ir0);
+        const work_item W = decode_item<LAYOUT>(P0, pt, lane, per_point, nr, nt, ir0);
+        const ucf_dev_params& P = item_params<MULTI>(P0, Pv, W.pidx + pbase, ppp);
+        bool need_lay1 = false;
+        for (int z = 0; z < nz; z++) need_lay1 |= (P.zLay[z] == 1);
         const double tD = tDv[W.it], rD = rDv[W.ir];
         const int sv = (LAYOUT == 1) ? svmin : svv[W.it];
         const double2* __restrict__ row = tab + (size_t)(per_point ? W.pidx : (W.ir * nsv + (sv - svmin))) * nabs;
@@ -996,7 +1009,7 @@ integrate_kernel(const ucf_dev_params P, int npts, int per_point, int nr, int ns
         const cplx p = cmake(sigma, UCF_PI * W.mlap / tee);                                     // invlap.f90:168
         const cplx lt = lap_time(P, p);
         const lane_consts LC = make_lane_consts(P, p, lt);
-        double2* __restrict__ sti = state + (size_t)pt * state_slots(P) * UCF_WAVE;
+        double2* __restrict__ sti = state + (size_t)pt * state_slots(P0) * UCF_WAVE;
         double2* __restrict__ areas = sti + (size_t)(R + 1) * nz * UCF_WAVE;
         for (int s = 0; s < (R + 1) * nz; s++) lds_st(lds, s, lane, cmake(0.0, 0.0));
         fast_common F;
@@ -1381,11 +1394,12 @@ size_t state_bytes_per_item(const ucf_dev_params& dp)
 
 // The transform stage for `nwork` work items of lane layout LAYOUT: [integrate_kernel ->] point_kernel.
 // ev0/ev1 (optional) bracket the dominant kernel: integrate_kernel when the flavour has one, else point_kernel.
-template <int LAYOUT>
-static int launch_transform(const ucf_dev_params& dp, int nwork, int per_point, int nr, int nsv, int svmin, const double* d_tD,
+template <int LAYOUT, bool MULTI>
+static int launch_transform_(const ucf_dev_params& dp, int nwork, int per_point, int nr, int nsv, int svmin, const double* d_tD,
                             const double* d_rD, const int* d_sv, const double* d_tab, double* d_h, double* d_dh,
                             ucf_stats* d_stats, int nt, int ir0, int nrc, double* d_totlap, double* d_glscr,
-                            double* d_state, int* d_ndone, void* stream, void* ev0, void* ev1)
+                            double* d_state, int* d_ndone, void* stream, void* ev0, void* ev1,
+                            const ucf_dev_params* d_params, int ppp, int pbase)
 {
     int* d_todo = d_ndone ? d_ndone + nwork : nullptr;     // [count | items]: the caller sizes d_ndone for 2 nwork + 1 ints
     const int fam = family_of(dp);
@@ -1407,9 +1421,9 @@ static int launch_transform(const ucf_dev_params& dp, int nwork, int per_point, 
 #define UCF_LAUNCH_I(F, W)                                                                                     \
     do {                                                                                                       \
         if (ilds > 64 * 1024)                                                                                  \
-            (void)hipFuncSetAttribute((const void*)integrate_kernel<F, LAYOUT, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ilds); \
-        hipLaunchKernelGGL((integrate_kernel<F, LAYOUT, W>), dim3((unsigned)nwork), block, ilds, s, dp, nwork, per_point, nr, nsv, svmin, \
-                           d_tD, d_rD, d_sv, (const double2*)d_tab, nt, ir0, (double2*)d_state, d_ndone, d_todo); \
+            (void)hipFuncSetAttribute((const void*)integrate_kernel<F, LAYOUT, W, MULTI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ilds); \
+        hipLaunchKernelGGL((integrate_kernel<F, LAYOUT, W, MULTI>), dim3((unsigned)nwork), block, ilds, s, dp, nwork, per_point, nr, nsv, svmin, \
+                           d_tD, d_rD, d_sv, (const double2*)d_tab, nt, ir0, (double2*)d_state, d_ndone, d_todo, d_params, ppp, pbase); \
     } while (0)
         const bool w5 = ilds * 20 <= 160 * 1024;
         switch (fam) {
@@ -1450,10 +1464,10 @@ static int launch_transform(const ucf_dev_params& dp, int nwork, int per_point, 
 #define UCF_LAUNCH(F)                                                                                          \
     do {                                                                                                       \
         if (lds > 64 * 1024)                                                                                   \
-            (void)hipFuncSetAttribute((const void*)point_kernel<F, LAYOUT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((point_kernel<F, LAYOUT>), grid, block, lds, s, dp, nwork, per_point, nr, nsv, svmin, d_tD, d_rD, d_sv, \
+            (void)hipFuncSetAttribute((const void*)point_kernel<F, LAYOUT, MULTI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((point_kernel<F, LAYOUT, MULTI>), grid, block, lds, s, dp, nwork, per_point, nr, nsv, svmin, d_tD, d_rD, d_sv, \
                            (const double2*)d_tab, d_h, d_dh, d_stats, nt, ir0, nrc, (double2*)d_totlap, (double2*)d_glscr,          \
-                           (double2*)d_state, (const int*)d_ndone, (const int*)d_todo);                        \
+                           (double2*)d_state, (const int*)d_ndone, (const int*)d_todo, d_params, ppp, pbase);  \
     } while (0)
     switch (fam) {
     case 0: UCF_LAUNCH(0); break;
@@ -1468,13 +1482,36 @@ static int launch_transform(const ucf_dev_params& dp, int nwork, int per_point, 
     return hipGetLastError() == hipSuccess ? UCF_OK : UCF_ERR_HIP;
 }
 
+// d_params != NULL: parameter-batched launch (per-point layouts of the fast flavour only), plan k owns points
+// [k ppp, (k+1) ppp) and reads d_params[k]; dp is plan 0's block
+template <int LAYOUT>
+static int launch_transform(const ucf_dev_params& dp, int nwork, int per_point, int nr, int nsv, int svmin, const double* d_tD,
+                            const double* d_rD, const int* d_sv, const double* d_tab, double* d_h, double* d_dh,
+                            ucf_stats* d_stats, int nt, int ir0, int nrc, double* d_totlap, double* d_glscr,
+                            double* d_state, int* d_ndone, void* stream, void* ev0, void* ev1,
+                            const ucf_dev_params* d_params = nullptr, int ppp = 1, int pbase = 0)
+{
+#if UCF_FAST
+    if (d_params) {
+        if (LAYOUT == 1 || !per_point) return UCF_ERR_BAD_ARGUMENT;
+        return launch_transform_<(LAYOUT == 1 ? 0 : LAYOUT), true>(dp, nwork, per_point, nr, nsv, svmin, d_tD, d_rD, d_sv, d_tab, d_h, d_dh, d_stats, nt,
+                                                                  ir0, nrc, d_totlap, d_glscr, d_state, d_ndone, stream, ev0, ev1, d_params, ppp, pbase);
+    }
+#else
+    if (d_params) return UCF_ERR_UNSUPPORTED;
+#endif
+    return launch_transform_<LAYOUT, false>(dp, nwork, per_point, nr, nsv, svmin, d_tD, d_rD, d_sv, d_tab, d_h, d_dh, d_stats, nt, ir0, nrc,
+                                            d_totlap, d_glscr, d_state, d_ndone, stream, ev0, ev1, nullptr, 1, 0);
+}
+
 // LAYOUT 0 (lane = Laplace sample, de Hoog in the same wave)
 int launch_points(const ucf_dev_params& dp, int npts, int per_point, int nr, int nsv, int svmin, const double* d_tD,
                   const double* d_rD, const int* d_sv, const double* d_tab, double* d_h, double* d_dh,
-                  ucf_stats* d_stats, void* stream, double* d_glscr, double* d_state, int* d_ndone)
+                  ucf_stats* d_stats, void* stream, double* d_glscr, double* d_state, int* d_ndone,
+                  const ucf_dev_params* d_params, int ppp, int pbase)
 {
     return launch_transform<0>(dp, npts, per_point, nr, nsv, svmin, d_tD, d_rD, d_sv, d_tab, d_h, d_dh, d_stats, 0, 0, 0,
-                               nullptr, d_glscr, d_state, d_ndone, stream, nullptr, nullptr);
+                               nullptr, d_glscr, d_state, d_ndone, stream, nullptr, nullptr, d_params, ppp, pbase);
 }
 
 // LAYOUT 1 (lane = time): transform kernel(s) over (radius chunk x time tiles x Laplace index), then de Hoog
@@ -1501,14 +1538,15 @@ int launch_grid_transposed(const ucf_dev_params& dp, int nt, int nr, int ir0, in
 // Same addressing as launch_points; d_h/d_dh/d_totlap point at this chunk of points.
 int launch_points_chunked(const ucf_dev_params& dp, int npts, int per_point, int nr, int nsv, int svmin, const double* d_tD,
                           const double* d_rD, const int* d_sv, const double* d_tab, double* d_totlap, double* d_h,
-                          double* d_dh, ucf_stats* d_stats, void* stream, double* d_glscr, double* d_state, int* d_ndone)
+                          double* d_dh, ucf_stats* d_stats, void* stream, double* d_glscr, double* d_state, int* d_ndone,
+                          const ucf_dev_params* d_params, int ppp, int pbase)
 {
     hipStream_t s = (hipStream_t)stream;
     const int nchunk = (dp.np + UCF_WAVE - 1) / UCF_WAVE;
     const long long nwork = (long long)npts * nchunk;
     if (nwork > 0x7fffffffLL) return UCF_ERR_BAD_ARGUMENT;
     int rc = launch_transform<2>(dp, (int)nwork, per_point, nr, nsv, svmin, d_tD, d_rD, d_sv, d_tab, d_h, d_dh, d_stats, 0, 0, 0,
-                                 d_totlap, d_glscr, d_state, d_ndone, stream, nullptr, nullptr);
+                                 d_totlap, d_glscr, d_state, d_ndone, stream, nullptr, nullptr, d_params, ppp, pbase);
     if (rc) return rc;
     hipLaunchKernelGGL(dehoog_points_kernel, dim3((unsigned)npts), dim3(UCF_WAVE), 0, s, dp, (long long)npts, 1, per_point, nr, 0, 0, d_tD,
                        (const double2*)d_totlap, d_h, d_dh, d_stats);

@@ -87,10 +87,12 @@ int launch_abscissae(const ucf_dev_params& dp, int nrows, int per_point, int nsv
                      const int* d_sv, double* d_tab, void* stream);
 int launch_points(const ucf_dev_params& dp, int npts, int per_point, int nr, int nsv, int svmin, const double* d_tD,
                   const double* d_rD, const int* d_sv, const double* d_tab, double* d_h, double* d_dh,
-                  ucf_stats* d_stats, void* stream, double* d_glscr, double* d_state, int* d_ndone);
+                  ucf_stats* d_stats, void* stream, double* d_glscr, double* d_state, int* d_ndone,
+                  const ucf_dev_params* d_params = nullptr, int ppp = 1, int pbase = 0);
 int launch_points_chunked(const ucf_dev_params& dp, int npts, int per_point, int nr, int nsv, int svmin, const double* d_tD,
                           const double* d_rD, const int* d_sv, const double* d_tab, double* d_totlap, double* d_h,
-                          double* d_dh, ucf_stats* d_stats, void* stream, double* d_glscr, double* d_state, int* d_ndone);
+                          double* d_dh, ucf_stats* d_stats, void* stream, double* d_glscr, double* d_state, int* d_ndone,
+                  const ucf_dev_params* d_params = nullptr, int ppp = 1, int pbase = 0);
 int launch_grid_transposed(const ucf_dev_params& dp, int nt, int nr, int ir0, int nrc, int svmin, const double* d_tD,
                            const double* d_rD, const double* d_tab, double* d_totlap, double* d_h, double* d_dh,
                            ucf_stats* d_stats, void* stream, void* ev0, void* ev1, double* d_glscr, double* d_state, int* d_ndone);
@@ -105,13 +107,15 @@ int launch_extrap(int n, int R, const double* d_x, const double* d_y, double* d_
 namespace ucf_fast {
 int launch_points_chunked(const ucf_dev_params& dp, int npts, int per_point, int nr, int nsv, int svmin, const double* d_tD,
                           const double* d_rD, const int* d_sv, const double* d_tab, double* d_totlap, double* d_h,
-                          double* d_dh, ucf_stats* d_stats, void* stream, double* d_glscr, double* d_state, int* d_ndone);
+                          double* d_dh, ucf_stats* d_stats, void* stream, double* d_glscr, double* d_state, int* d_ndone,
+                  const ucf_dev_params* d_params = nullptr, int ppp = 1, int pbase = 0);
 int launch_grid_transposed(const ucf_dev_params& dp, int nt, int nr, int ir0, int nrc, int svmin, const double* d_tD,
                            const double* d_rD, const double* d_tab, double* d_totlap, double* d_h, double* d_dh,
                            ucf_stats* d_stats, void* stream, void* ev0, void* ev1, double* d_glscr, double* d_state, int* d_ndone);
 int launch_points(const ucf_dev_params& dp, int npts, int per_point, int nr, int nsv, int svmin, const double* d_tD,
                   const double* d_rD, const int* d_sv, const double* d_tab, double* d_h, double* d_dh,
-                  ucf_stats* d_stats, void* stream, double* d_glscr, double* d_state, int* d_ndone);
+                  ucf_stats* d_stats, void* stream, double* d_glscr, double* d_state, int* d_ndone,
+                  const ucf_dev_params* d_params = nullptr, int ppp = 1, int pbase = 0);
 int launch_samples(const ucf_dev_params& dp, int n_a, const double* d_a, double rD, const double* d_p, double* d_fp,
                    void* stream);
 // bytes of integrate_kernel -> point_kernel state per work item (0 where the flavour / model has no integrate_kernel)
