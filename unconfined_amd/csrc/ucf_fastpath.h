@@ -76,6 +76,21 @@ UCF_DEV fprim prim(double x, double y)
     sincos_medium_(y, &f.sn, &f.cs);     // |y| < 1e6: fast_eta() vouches for it
     return f;
 }
+// primitive of x1 - x2, y1 - y2 from the primitives of (x1, y1) and (x2, y2), 0 <= x2 <= x1: the real
+// exponentials divide, the angles subtract (no cancellation in either; sinh of a small difference loses
+// relative, not absolute, accuracy, which is all cosh/sinh products of complex arguments need)
+UCF_DEV fprim prim_difference(const fprim& a, const fprim& b)
+{
+    fprim f;
+    const double e = (a.ch + a.sh) * b.ei;            // e^(x1 - x2)
+    const double ei = a.ei * (b.ch + b.sh);
+    f.ei = ei;
+    f.ch = 0.5 * (e + ei);
+    f.sh = 0.5 * (e - ei);
+    f.sn = __builtin_fma(a.sn, b.cs, -(a.cs * b.sn));
+    f.cs = __builtin_fma(a.cs, b.cs, a.sn * b.sn);
+    return f;
+}
 UCF_DEV cplx pcosh(const fprim& f) { return cmake(f.ch * f.cs, f.sh * f.sn); }
 UCF_DEV cplx psinh(const fprim& f) { return cmake(f.sh * f.cs, f.ch * f.sn); }
 // exp(-(x+iy)) for x >= 0
@@ -129,6 +144,8 @@ UCF_DEV lane_consts make_lane_consts(const ucf_dev_params& P, cplx p, cplx lt)
 
 struct fast_common {
     cplx th, eta, ff1, ff2, inv_she, she, che, top, g3, inv_den, ex1;   // ex1 = exp(-eta)
+    fprim p1;            // primitive of eta itself (valid when have_p1)
+    bool have_p1;
     cplx fd_s1;          // FD: sigma(1)
     bool small_eta, fd_use;
     bool any_small, any_large;   // wave-uniform: some lane on the cosh/sinh form, some lane on the exponential form
@@ -157,20 +174,25 @@ UCF_DEV bool fast_eta(const ucf_dev_params& P, const lane_consts& L, double a, f
 }
 
 // z-independent part (after fast_eta said yes for every lane of the wave)
-template <int FAMILY>
-UCF_DEV void fast_common_terms(const ucf_dev_params& P, const lane_consts& L, double a, bool need_lay1, fast_common& S)
+// FOLD: the plan is known to be fully penetrating (fold_dD and fold_lD1), so that none of the screen terms is even
+// compiled in (the launcher picks the instantiation; FOLD = false handles every plan)
+template <int FAMILY, bool FOLD = false>
+UCF_DEV void fast_common_terms(const ucf_dev_params& P, const lane_consts& L, double a, bool need_lay1_in, fast_common& S)
 {
     const double a2 = a * a;
     const bool hantush = !(FAMILY == 2 && P.model == 4);
-    const bool z1 = P.fold_dD != 0, z2 = P.fold_lD1 != 0;
+    const bool z1 = FOLD || P.fold_dD != 0, z2 = FOLD || P.fold_lD1 != 0;
+    const bool need_lay1 = FOLD ? false : need_lay1_in;           // a fully penetrating screen has no layer below it
     // the water-table closure switches to its exponential form at Re(eta) >= maxexp (:84) and then needs neither
     // cosh(eta) nor sinh(eta): decide per wave what has to be evaluated at all
     S.small_eta = (FAMILY != 2) || (S.eta.re < P.maxexp);                                       // :84
     S.any_small = (FAMILY != 2) || (__builtin_amdgcn_ballot_w64(S.small_eta) != 0);
     S.any_large = (FAMILY == 2) && (__builtin_amdgcn_ballot_w64(!S.small_eta) != 0);
     const bool need_p1 = (hantush && (!(z1 && z2) || need_lay1)) || FAMILY == 4 || (FAMILY == 2 && S.any_small);
+    S.have_p1 = need_p1 && !z2;      // kept only where fast_hantush_z derives the primitive of eta (1 - zD) from it
     if (need_p1) {
         const fprim p1 = prim(S.eta.re, S.eta.im);
+        if (!z2) S.p1 = p1;
         S.che = pcosh(p1);
         S.she = psinh(p1);
         S.ex1 = pexpneg(p1);
@@ -245,14 +267,16 @@ UCF_DEV bool fast_prepare(const ucf_dev_params& P, const lane_consts& L, double 
 }
 
 // Hantush factor at depth zD (:133-202); chz = cosh(eta*zD) is returned for the closure
-template <int FAMILY>
-UCF_DEV cplx fast_hantush_z(const ucf_dev_params& P, const fast_common& S, double zD, int lay, cplx* chz_out,
+template <int FAMILY, bool FOLD = false>
+UCF_DEV cplx fast_hantush_z(const ucf_dev_params& P, const fast_common& S, double zD, int lay_in, cplx* chz_out,
                             cplx* exz_out)
 {
-    const bool z1 = P.fold_dD != 0, z2 = P.fold_lD1 != 0;
+    const bool z1 = FOLD || P.fold_dD != 0, z2 = FOLD || P.fold_lD1 != 0;
+    const int lay = FOLD ? 2 : lay_in;                            // everything is beside the screen
     const bool need_chz = (lay == 1) || !z1 || (FAMILY == 2 && S.any_small) || FAMILY == 4;
     cplx chz = cmake(1.0, 0.0);
-    if (need_chz) chz = pcosh(prim(S.eta.re * zD, S.eta.im * zD));
+    fprim pz;
+    if (need_chz) { pz = prim(S.eta.re * zD, S.eta.im * zD); chz = pcosh(pz); }
     *chz_out = chz;
     cplx udp;
     if (lay == 1) {
@@ -261,7 +285,13 @@ UCF_DEV cplx fast_hantush_z(const ucf_dev_params& P, const fast_common& S, doubl
         cplx g2 = cmake(0.0, 0.0);
         const bool need_1z = !z2 || (FAMILY == 2 && S.any_large);
         fprim p1z;
-        if (need_1z) { const double c = 1.0 - zD; p1z = prim(S.eta.re * c, S.eta.im * c); }
+        if (need_1z) {
+#ifndef UCF_NO_PRIM_DIFFERENCE
+            if (need_chz && S.have_p1 && zD >= 0.0 && zD <= 1.0) p1z = prim_difference(S.p1, pz);     // eta (1 - zD)
+            else
+#endif
+            { const double c = 1.0 - zD; p1z = prim(S.eta.re * c, S.eta.im * c); }
+        }
         if (FAMILY == 2 && S.any_large) *exz_out = pexpneg(p1z);                                // exp(eta*(zD-1))
         if (!(z1 && z2)) {
             cplx num = cmake(0.0, 0.0);
@@ -280,15 +310,15 @@ UCF_DEV cplx fast_hantush_z(const ucf_dev_params& P, const fast_common& S, doubl
     return cscale(cmul(udp, S.th), P.inv_bD);                                                   // :200
 }
 
-template <int FAMILY>
+template <int FAMILY, bool FOLD = false>
 UCF_DEV cplx fast_sample_z(const ucf_dev_params& P, const fast_common& S, int iz)
 {
     const double zD = P.zD[iz];
     const int lay = P.zLay[iz];
     cplx chz, exz = cmake(0.0, 0.0);
-    if (FAMILY == 1) return fast_hantush_z<1>(P, S, zD, lay, &chz, &exz);
+    if (FAMILY == 1) return fast_hantush_z<1, FOLD>(P, S, zD, lay, &chz, &exz);
     if (FAMILY == 4) {
-        const cplx sH = fast_hantush_z<4>(P, S, zD, lay, &chz, &exz);
+        const cplx sH = fast_hantush_z<4, FOLD>(P, S, zD, lay, &chz, &exz);
         return S.fd_use ? cadd(sH, cmul(S.fd_s1, chz)) : sH;                                    // :522-525
     }
     cplx u;
@@ -297,7 +327,7 @@ UCF_DEV cplx fast_sample_z(const ucf_dev_params& P, const fast_common& S, int iz
         if (S.any_small) chz = pcosh(prim(S.eta.re * zD, S.eta.im * zD));
         if (S.any_large) { const double c = 1.0 - zD; exz = pexpneg(prim(S.eta.re * c, S.eta.im * c)); }
     } else {
-        u = fast_hantush_z<2>(P, S, zD, lay, &chz, &exz);
+        u = fast_hantush_z<2, FOLD>(P, S, zD, lay, &chz, &exz);
         if (S.any_large && lay == 1) { const double c = 1.0 - zD; exz = pexpneg(prim(S.eta.re * c, S.eta.im * c)); }
     }
     if (S.small_eta) return csub(u, cmul(cmul(S.top, chz), S.inv_den));                         // :85-87
