@@ -978,6 +978,9 @@ point_kernel(const ucf_dev_params P0, int npts, int per_point, int nr, int nsv, 
 // The level sums, the running interval area and the finished interval areas go to the item's state
 // (HBM, written once, coalesced 1 KB per slot); point_kernel resumes from there: remaining abscissae
 // with the generic evaluator (the overflow regime the fast one leaves alone), Richardson, Wynn, de Hoog.
+#ifndef UCF_FOLD_WAVES
+#define UCF_FOLD_WAVES 5
+#endif
 // WAVES per SIMD the register budget is cut for: 5 when the LDS footprint lets 20 waves share a CU (nz = 1), else 4
 template <int FAMILY, int LAYOUT, int WAVES, bool MULTI, bool FOLD>
 __global__ void __launch_bounds__(UCF_WAVE, WAVES)
@@ -1431,7 +1434,7 @@ static int launch_transform_(const ucf_dev_params& dp, int nwork, int per_point,
         switch (fam) {
         case 1: if (fold) UCF_LAUNCH_I(1, 4, true); else UCF_LAUNCH_I(1, 4, false); break;
         case 2:
-            if (fold) { if (w5) UCF_LAUNCH_I(2, 5, true); else UCF_LAUNCH_I(2, 4, true); }
+            if (fold) { if (w5) UCF_LAUNCH_I(2, UCF_FOLD_WAVES, true); else UCF_LAUNCH_I(2, 4, true); }
 #ifdef UCF_UNFOLDED_W5
             else { if (w5) UCF_LAUNCH_I(2, 5, false); else UCF_LAUNCH_I(2, 4, false); }
 #else
