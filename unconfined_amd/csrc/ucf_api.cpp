@@ -231,6 +231,20 @@ int fill_call_params(const ucf_plan* plan, int nz, const double* zD, const int* 
         cmax = std::fmax(cmax, std::fabs(dp.dD1 - zD[i]));
     }
     dp.fast_im_max = 1.0e6 / cmax;
+    if (!(dp.fold_dD && dp.fold_lD1)) {
+        // products the reference forms (laplace_hankel_solutions.f90:179-180 and the zD = 1 evaluation of :81):
+        // sinh(eta dD) cosh(eta zD), sinh(eta lD1) cosh(eta (1-zD)), sinh(eta dD) cosh(eta): exponents eta*(c1 + c2)
+        double cprod = 1.0 + std::fabs(dp.dD);
+        for (int i = 0; i < nz; i++) {
+            if (zLay[i] == 1) continue;                       // below the screen: g(3) cosh(eta zD), no such product
+            cprod = std::fmax(cprod, std::fabs(dp.dD) + std::fabs(zD[i]));
+            cprod = std::fmax(cprod, std::fabs(dp.lD1) + std::fabs(1.0 - zD[i]));
+        }
+        dp.fast_eta_max = 700.0 / cprod;
+        if (dp.model == 6 && dp.MNtype == 2 && dp.fast_eta_max > 350.0) dp.fast_eta_max = 350.0;   // FD closure: cosh(eta)/h^2 terms
+    }
+    static const double eta_cap = [] { const char* e = std::getenv("UCF_FAST_ETA_MAX"); return e ? std::atof(e) : 0.0; }();
+    if (eta_cap > 0.0 && dp.fast_eta_max > eta_cap) dp.fast_eta_max = eta_cap;      // diagnostic: hand more of the range to the generic evaluator
     return UCF_OK;
 }
 
@@ -382,7 +396,10 @@ int ucf_plan_create(const ucf_params* Pin, ucf_plan** out)
     dp.fold_dD = (D.dD == 0.0);                       // sinh(eta*0) == 0 exactly
     dp.fold_lD1 = (dp.lD1 == 0.0);
     dp.share_g1top = ((dp.dD1 - 1.0) == -D.dD);       // cosh(eta*(dD1-1)) == cosh(eta*dD) bit for bit
-    // no cosh/sinh (<= e^{Re eta}) nor product of two of them (<= e^{2 Re eta}) may overflow on the fast path
+    // the fast path is only used where the REFERENCE's own intermediates stay finite (beyond that its results are
+    // shaped by Inf/NaN and the in-band rules, which the generic evaluator reproduces): no cosh/sinh (<= e^{Re eta})
+    // and none of the products of two of them that the reference forms may overflow.  Refined per call in
+    // fill_call_params (the products depend on the depths).
     dp.fast_eta_max = (dp.fold_dD && dp.fold_lD1) ? 700.0 : 350.0;
     dp.ts_x = pl->d_tables + o_tsx;
     dp.ts_w = pl->d_tables + o_tsw;
