@@ -445,6 +445,21 @@ def test_parameter_batched_sweep(engine):
         h1, dh1 = pl.drawdown(tD, rD, pl.split_vector(tD), zD, pl.zlay(zD))
         assert np.array_equal(h[k], h1 * D.Hc) and np.array_equal(dh[k], dh1 * D.Hc), k
     assert np.abs(h[0] - h[11]).max() > 1e-3        # the parameter sets do differ
+    # geometry varies too (the depths fall into different layers from plan to plan), still one launch sequence;
+    # and a batch that cannot share one (different M) goes plan by plan -- same results either way
+    geo = [engine.Plan(params_from_deck(dk.replace(l=dk.l * f, d=dk.d * g, Kr=dk.Kr * (1 + 0.1 * i))), mode="fast")
+           for i, (f, g) in enumerate([(1.0, 1.0), (0.55, 1.0), (1.0, 4.5), (0.9, 0.2), (2.2, 0.5)])]
+    zg = np.array([145.7, 100.0, 20.0])
+    lays = {tuple(pl.zlay(zg / pl.derived.Lc)) for pl in geo}
+    assert len(lays) > 1, lays
+    mixed = [engine.Plan(params_from_deck(dk.replace(M=20 + 3 * i, Kr=dk.Kr * (1 + 0.2 * i))), mode="fast") for i in range(3)]
+    for group in (geo, mixed):
+        hg, dhg = engine.drawdown_multi(group, t, r, zg)
+        for k, pl in enumerate(group):
+            D = pl.derived
+            tD, rD, zD = t / D.Tc, r / D.Lc, zg / D.Lc
+            h1, dh1 = pl.drawdown(tD, rD, pl.split_vector(tD), zD, pl.zlay(zD))
+            assert np.array_equal(hg[k], h1 * D.Hc, equal_nan=True) and np.array_equal(dhg[k], dh1 * D.Hc, equal_nan=True), k
 
 
 def test_smoke_entry():
