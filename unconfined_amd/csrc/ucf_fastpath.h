@@ -21,7 +21,7 @@ struct fprim {
     double ch, sh, ei, sn, cs;    // cosh(x), sinh(x), exp(-|x|), sin(y), cos(y)
 };
 
-// exp(x), 0 <= x <= 709.  k = rint(x/ln2), r = x - k ln2 (two-part), degree-13 Taylor in r
+// exp(x), |x| <= 709 (underflows to 0 / subnormals below that like ldexp does).  k = rint(x/ln2), r = x - k ln2 (two-part), degree-13 Taylor in r
 // (|r| <= 0.3466: truncation 4e-18), scaled by 2^k.
 UCF_DEV double exp_pos(double x)
 {
@@ -95,6 +95,15 @@ UCF_DEV cplx pcosh(const fprim& f) { return cmake(f.ch * f.cs, f.sh * f.sn); }
 UCF_DEV cplx psinh(const fprim& f) { return cmake(f.sh * f.cs, f.ch * f.sn); }
 // exp(-(x+iy)) for x >= 0
 UCF_DEV cplx pexpneg(const fprim& f) { return cmake(f.ei * f.cs, -(f.ei * f.sn)); }
+
+// exp(-(x + iy)) for x >= 0 on its own: no reciprocal, no cosh/sinh
+UCF_DEV cplx expneg_direct(double x, double y)
+{
+    const double ei = exp_pos(-x);
+    double sn, cs;
+    sincos_medium_(y, &sn, &cs);
+    return cmake(ei * cs, -(ei * sn));
+}
 
 // 1/z without scaling: |z| in [1e-150, 1e150]
 UCF_DEV cplx cinv_plain(cplx z)
@@ -283,8 +292,12 @@ UCF_DEV cplx fast_hantush_z(const ucf_dev_params& P, const fast_common& S, doubl
         udp = cmul(S.g3, chz);                                                                  // :188
     } else {
         cplx g2 = cmake(0.0, 0.0);
-        const bool need_1z = !z2 || (FAMILY == 2 && S.any_large);
+        const bool need_1z = !z2;
         fprim p1z;
+        if (z2 && FAMILY == 2 && S.any_large) {                  // only exp(eta (zD - 1)) is wanted
+            const double c = 1.0 - zD;
+            *exz_out = expneg_direct(S.eta.re * c, S.eta.im * c);
+        }
         if (need_1z) {
 #ifndef UCF_NO_PRIM_DIFFERENCE
             if (need_chz && S.have_p1 && zD >= 0.0 && zD <= 1.0) p1z = prim_difference(S.p1, pz);     // eta (1 - zD)
@@ -292,7 +305,7 @@ UCF_DEV cplx fast_hantush_z(const ucf_dev_params& P, const fast_common& S, doubl
 #endif
             { const double c = 1.0 - zD; p1z = prim(S.eta.re * c, S.eta.im * c); }
         }
-        if (FAMILY == 2 && S.any_large) *exz_out = pexpneg(p1z);                                // exp(eta*(zD-1))
+        if (!z2 && FAMILY == 2 && S.any_large) *exz_out = pexpneg(p1z);                         // exp(eta*(zD-1))
         if (!(z1 && z2)) {
             cplx num = cmake(0.0, 0.0);
             if (!z1) num = cmul(S.ff1, chz);
@@ -325,10 +338,10 @@ UCF_DEV cplx fast_sample_z(const ucf_dev_params& P, const fast_common& S, int iz
     if (P.model == 4) {
         u = S.th;
         if (S.any_small) chz = pcosh(prim(S.eta.re * zD, S.eta.im * zD));
-        if (S.any_large) { const double c = 1.0 - zD; exz = pexpneg(prim(S.eta.re * c, S.eta.im * c)); }
+        if (S.any_large) { const double c = 1.0 - zD; exz = expneg_direct(S.eta.re * c, S.eta.im * c); }
     } else {
         u = fast_hantush_z<2, FOLD>(P, S, zD, lay, &chz, &exz);
-        if (S.any_large && lay == 1) { const double c = 1.0 - zD; exz = pexpneg(prim(S.eta.re * c, S.eta.im * c)); }
+        if (S.any_large && lay == 1) { const double c = 1.0 - zD; exz = expneg_direct(S.eta.re * c, S.eta.im * c); }
     }
     if (S.small_eta) return csub(u, cmul(cmul(S.top, chz), S.inv_den));                         // :85-87
     return csub(u, cmul(cmul(S.top, exz), S.inv_den));                                          // :89-91
