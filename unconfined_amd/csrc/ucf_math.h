@@ -85,13 +85,14 @@ __device__ __noinline__ static cplx cdiv_recover(double a, double b, double c, d
 }
 
 #if UCF_FAST
-// 1/x to < 1 ulp: hardware estimate (v_rcp_f64) + two Newton steps (fast flavour only)
+// 1/x to < 1 ulp (fast flavour only): hardware estimate (v_rcp_f64, measured 2^-24.4 on gfx950,
+// tools/ubench/acc.hip) and ONE third-order step r (1 + e + e^2), e = 1 - x r: residual e^3 = 2^-73, one
+// instruction less than two Newton steps
 UCF_DEV double fast_rcp(double x)
 {
-    double r = __builtin_amdgcn_rcp(x);
-    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
-    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
-    return r;
+    const double r = __builtin_amdgcn_rcp(x);
+    const double e = __builtin_fma(-x, r, 1.0);
+    return __builtin_fma(r, __builtin_fma(e, e, e), r);
 }
 
 // a*b + C, a*C and a + C with the 64-bit constant C held in an SGPR pair.  Left to itself the compiler
