@@ -198,9 +198,11 @@ UCF_DEV bool c_is_finite(cplx z)
 #define UCF_DBL_MAX 1.7976931348623157e308
 
 #if UCF_FAST
-// sin and cos together, |y| < 2^20*pi/2: argument reduction of fdlibm's __ieee754_rem_pio2
-// (medium range, always carried to the second stage: 118 bits of pi/2) + the fdlibm/msun kernels
-// __kernel_sin / __kernel_cos on the reduced (head, tail).  < 1 ulp.  Larger arguments go to libm.
+// sin and cos together, |y| < 2^20*pi/2: first stage of fdlibm's __ieee754_rem_pio2 (pi/2 = pio2_1 + pio2_1t,
+// 86 bits: the reduced argument is good to ~1e-20 ABSOLUTE for |y| < 1e6, i.e. sin and cos to < 1 ulp except
+// within ~1e-4 of their zeros, where the error stays below 1e-20 absolute -- all a cosh/sinh of a complex
+// argument can use) + the fdlibm/msun kernels __kernel_sin / __kernel_cos on (head, tail).
+// Larger arguments go to libm.
 __device__ __noinline__ static double2 sincos_huge_(double y) { double s, c; sincos(y, &s, &c); return make_double2(s, c); }
 
 // |x| < 1e6 (the caller's business)
@@ -209,13 +211,10 @@ UCF_DEV void sincos_medium_(double x, double* sn, double* cs)
     const int salt = __builtin_amdgcn_readfirstlane(__double2hiint(x));
 #define K(c) UCF_KHERE(c, salt)
     const double fn = __builtin_rint(mulk(x, K(6.36619772367581382433e-01)));
-    double r = __builtin_fma(-fn, 1.57079632673412561417e+00, x);          // exact (33-bit constant)
-    const double t = r;
-    double w = mulk(fn, K(6.07710050630396597660e-11));                    // pio2_2
-    r = t - w;
-    w = __builtin_fma(fn, 2.02226624879595063154e-21, -((t - r) - w));     // pio2_2t
+    const double r = __builtin_fma(-fn, 1.57079632673412561417e+00, x);    // pio2_1: exact (33-bit constant, |fn| < 2^20)
+    const double w = mulk(fn, K(6.07710050650619224932e-11));              // pio2_1t = pi/2 - pio2_1
     const double y0 = r - w;
-    const double y1 = (r - y0) - w;
+    const double y1 = (r - y0) - w;                                        // (y0, y1) = x - fn pi/2 to ~1e-20 absolute
     const double z = y0 * y0;
     // __kernel_sin(y0, y1, 1)
     const double v = z * y0;
