@@ -21,8 +21,8 @@ struct fprim {
     double ch, sh, ei, sn, cs;    // cosh(x), sinh(x), exp(-|x|), sin(y), cos(y)
 };
 
-// exp(x), |x| <= 709 (underflows to 0 / subnormals below that like ldexp does).  k = rint(x/ln2), r = x - k ln2 (two-part), degree-13 Taylor in r
-// (|r| <= 0.3466: truncation 4e-18), scaled by 2^k.
+// exp(x), |x| <= 709 (underflows to 0 / subnormals below that like ldexp does).  k = rint(x/ln2), r = x - k ln2 (two-part),
+// degree-11 near-minimax polynomial in r, scaled by 2^k.
 UCF_DEV double exp_pos(double x)
 {
 #ifdef UCF_EXP_LOCAL_CONSTANTS
@@ -34,18 +34,18 @@ UCF_DEV double exp_pos(double x)
     const double k = __builtin_rint(mulk(x, K(1.4426950408889634074)));
     double r = __builtin_fma(-k, 6.93147180369123816490e-01, x);
     r = __builtin_fma(-k, 1.90821492927058770002e-10, r);
-    double q = addk(mulk(r, K(1.0 / 6227020800.0)), K(1.0 / 479001600.0));
-    q = fmak(q, r, K(1.0 / 39916800.0));
-    q = fmak(q, r, K(1.0 / 3628800.0));
-    q = fmak(q, r, K(1.0 / 362880.0));
-    q = fmak(q, r, K(1.0 / 40320.0));
-    q = fmak(q, r, K(1.0 / 5040.0));
-    q = fmak(q, r, K(1.0 / 720.0));
-    q = fmak(q, r, K(1.0 / 120.0));
-    q = fmak(q, r, K(1.0 / 24.0));
-    q = fmak(q, r, K(1.0 / 6.0));
+    // 1 + r + r^2 s(r), s of degree 9 interpolating (e^r - 1 - r)/r^2 at the Chebyshev nodes of |r| <= 0.34665
+    // (computed in 70-digit arithmetic): max relative error 1.6e-17 with these double coefficients
+    double q = addk(mulk(r, K(2.5100397137931663e-08)), K(2.762010358488696e-07));
+    q = fmak(q, r, K(2.755726843551756e-06));
+    q = fmak(q, r, K(2.4801521264122017e-05));
+    q = fmak(q, r, K(0.00019841269863069374));
+    q = fmak(q, r, K(0.0013888888917234206));
+    q = fmak(q, r, K(0.008333333333330058));
+    q = fmak(q, r, K(0.04166666666662409));
+    q = fmak(q, r, K(0.16666666666666669));
+    q = fmak(q, r, K(0.5000000000000001));
 #undef K
-    q = __builtin_fma(q, r, 0.5);
     q = __builtin_fma(q, r, 1.0);
     q = __builtin_fma(q, r, 1.0);
     return ldexp(q, (int)k);
