@@ -672,6 +672,83 @@ UCF_DEV cplx wynn_lane(lds_c* colA, lds_c* colB, int nin, int lane, int* status)
     return acc;
 }
 
+// The same algorithm with both epsilon columns in registers (fully unrolled over NMAX >= nin terms, every step
+// guarded per lane by the reference's own loop bounds): no LDS round trips, which is what limits finish_kernel.
+// series[i] holds term i+1 on entry.
+template <int NMAX>
+UCF_DEV cplx wynn_regs(const cplx (&series)[NMAX], int nin, int* status)
+{
+    cplx A[NMAX], B[NMAX];
+    int ns = nin;
+    int stat = 0;
+    bool cut = false;
+    cplx run = cmake(0.0, 0.0);
+#pragma unroll
+    for (int i = 1; i <= NMAX; i++) {                                                           // :140-163
+        A[i - 1] = cmake(0.0, 0.0);
+        B[i - 1] = cmake(0.0, 0.0);                                                             // :166
+        if (i <= nin && !cut) {
+            const cplx sv = series[i - 1];
+            if (!c_is_finite(sv)) {
+                ns = i - 1;
+                stat = (ns < 4) ? 2 : 1;
+                cut = true;
+            } else {
+                run = (i == 1) ? sv : cadd(run, sv);
+                A[i - 1] = run;
+            }
+        }
+    }
+    if (stat == 2) {
+        *status = 2;
+        return cmake((double)(-999999.9f), 0.0);                                                // :148
+    }
+    cplx acc = cmake(0.0, 0.0);
+    bool done = false;
+#pragma unroll
+    for (int j = 0; j <= NMAX - 2; j++) {                                                       // :169-181
+        const int count = ns - (j + 1);
+#pragma unroll
+        for (int m = 1; m <= NMAX - 1 - j; m++) {
+            if (!done && m <= count) {
+                // new(m) = prev(m+1) + 1/(cur(m+1) - cur(m)); the new column overwrites prev's storage
+                const cplx hi = (j & 1) ? B[m] : A[m];
+                const cplx lo = (j & 1) ? B[m - 1] : A[m - 1];
+                const cplx pv = (j & 1) ? A[m] : B[m];
+                const cplx denom = csub(hi, lo);
+                cplx nv = pv;
+                bool ok;
+#if UCF_FAST
+                const double d2 = __builtin_fma(denom.re, denom.re, denom.im * denom.im);
+                if (d2 > UCF_EPS * UCF_EPS && d2 < 1.0e300) {
+                    const double r = fast_rcp(d2);
+                    nv = cmake(__builtin_fma(denom.re, r, pv.re), __builtin_fma(-denom.im, r, pv.im));
+                    ok = true;
+                } else if (cabs_(denom) > UCF_EPS) {             // huge or non-finite difference: exact reference path
+                    nv = cadd(pv, rdiv(1.0, denom));
+                    ok = true;
+                } else {
+                    ok = false;
+                }
+#else
+                ok = cabs_(denom) > UCF_EPS;                                                    // :172
+                if (ok) nv = cadd(pv, rdiv(1.0, denom));                                        // :173
+#endif
+                if (ok) {
+                    if (j & 1) A[m - 1] = nv; else B[m - 1] = nv;
+                } else {
+                    acc = hi;                                                                   // :175
+                    done = true;
+                    stat = 3;
+                }
+            }
+        }
+    }
+    if (!done) acc = A[1];        // eps(2,ns-2) [ns even] or eps(2,ns-3) [ns odd]: both even columns
+    *status = stat;
+    return acc;
+}
+
 // ------------------------------------------------------------- integration.f90:192-237
 // Per-lane Neville extrapolation to x = 0.  colC[(i*strideC)][lane] holds y(i+1) (destroyed),
 // colD is half-wave scratch.  x is wave-uniform.
@@ -797,7 +874,8 @@ UCF_DEV work_item decode_item(const ucf_dev_params& P, int pt, int lane, int per
 // J0-interval areas, then the transform goes to the workspace (LAYOUT 1, 2) or straight through de Hoog
 // (LAYOUT 0).  accTS: [R][nz] level sums in LDS; the finished areas come from LDS (accGL) or global memory.
 // PART lanes of the wave work at a time on the scratch columns scr ([max(2 nacc, R)][PART]).
-template <int LAYOUT, int PART>
+#define UCF_WYNN_REGS 12      /* terms the register-resident Wynn-epsilon of finish_kernel holds */
+template <int LAYOUT, int PART, bool WREG = false>
 UCF_DEV void finish_item(const ucf_dev_params& P, lds_c* accTS, lds_c* scr, const lds_c* accGL,
                          const double2* __restrict__ areas, double arg, const work_item& W, int pt, double tD, double tee,
                          cplx p, ucf_stats* st, int nt, int ir0, double2* __restrict__ totlap, double* __restrict__ hout,
@@ -814,6 +892,22 @@ UCF_DEV void finish_item(const ucf_dev_params& P, lds_c* accTS, lds_c* scr, cons
         cplx finint = lds_ld(accTS, z, lane);
         cplx infint = cmake(0.0, 0.0);
         int wst = 0;
+        if (WREG) {
+            // finish_kernel, nacc <= UCF_WYNN_REGS: the areas go from the state straight into registers
+            cplx ser[UCF_WYNN_REGS];
+#pragma unroll
+            for (int jj = 0; jj < UCF_WYNN_REGS; jj++) {
+                ser[jj] = cmake(0.0, 0.0);
+                if (jj < nacc) {
+                    const double2 v = areas[(size_t)(jj * nz + z) * UCF_WAVE + lane];
+                    ser[jj] = cmake(v.x, v.y);
+                    any |= (cabs_(ser[jj]) > 0.0);                                              // :209
+                }
+            }
+            for (int part = 0; part < UCF_WAVE / PART; part++)
+                if ((lane / PART) == part && R > 1) finint = extrap_lane<PART>(accTS + (size_t)z * UCF_WAVE, nz, scr, P.hv, R, lane);
+            if (any) infint = wynn_regs<UCF_WYNN_REGS>(ser, nacc, &wst);
+        } else
         for (int part = 0; part < UCF_WAVE / PART; part++) {
             if ((lane / PART) == part) {
                 if (R > 1) finint = extrap_lane<PART>(accTS + (size_t)z * UCF_WAVE, nz, scr, P.hv, R, lane);
@@ -1079,8 +1173,8 @@ integrate_kernel(const ucf_dev_params P0, int npts, int per_point, int nr, int n
 // Tail of every work item integrate_kernel completed (all of them outside the overflow regime): state ->
 // finish_item.  Model independent and small, so it runs at full occupancy; PART is chosen at launch from the
 // LDS footprint ((R+1) nz slots of level sums + max(2 nacc, R) scratch columns of PART lanes).
-template <int LAYOUT, int PART>
-__global__ void __launch_bounds__(UCF_WAVE, LAYOUT == 0 ? 3 : 4)      // LAYOUT 0 carries de Hoog
+template <int LAYOUT, int PART, bool WREG>
+__global__ void __launch_bounds__(UCF_WAVE, (LAYOUT == 0 || WREG) ? 3 : 4)      // LAYOUT 0 carries de Hoog, WREG the epsilon table
 finish_kernel(const ucf_dev_params P, int npts, int per_point, int nr, int nsv, int svmin,
               const double* __restrict__ tDv, const double* __restrict__ rDv, const int* __restrict__ svv,
               double* __restrict__ hout, double* __restrict__ dhout, ucf_stats* st, int nt, int ir0,
@@ -1103,8 +1197,8 @@ finish_kernel(const ucf_dev_params P, int npts, int per_point, int nr, int nsv, 
         const double arg = P.j0z[sv - 1] / rD;                                                  // driver.f90:120
         const double2* __restrict__ sti = state + (size_t)pt * state_slots(P) * UCF_WAVE;
         for (int s = 0; s < R * nz; s++) lds[s * UCF_WAVE + lane] = sti[(size_t)s * UCF_WAVE + lane];
-        finish_item<LAYOUT, PART>(P, accTS, scr, nullptr, sti + (size_t)(R + 1) * nz * UCF_WAVE, arg, W, pt, tD, tee, p, st, nt, ir0,
-                                  totlap, hout, dhout);
+        finish_item<LAYOUT, PART, WREG>(P, accTS, scr, nullptr, sti + (size_t)(R + 1) * nz * UCF_WAVE, arg, W, pt, tD, tee, p, st, nt, ir0,
+                                        totlap, hout, dhout);
     }
 }
 #endif
@@ -1447,25 +1541,28 @@ static int launch_transform_(const ucf_dev_params& dp, int nwork, int per_point,
         if (ev1) (void)hipEventRecord((hipEvent_t)ev1, s);
         if (hipGetLastError() != hipSuccess) return UCF_ERR_HIP;
         ev0 = ev1 = nullptr;
-        // tails of the completed items: the widest scratch part that still leaves 4 waves per CU (measured on C2:
+        // tails of the completed items.  nacc <= UCF_WYNN_REGS: epsilon table in registers, LDS only for the level sums
+        // and the Neville column; else the widest scratch part that still leaves 4 waves per CU (measured on C2:
         // 4.8 / 3.6 / 3.1 ms for parts of 16 / 32 / 64 lanes)
-        const size_t scols = (size_t)(2 * dp.nacc > dp.R ? 2 * dp.nacc : dp.R);
+        const bool wreg = dp.nacc <= UCF_WYNN_REGS && !ucf_finish_part;
+        const size_t scols = wreg ? (size_t)dp.R : (size_t)(2 * dp.nacc > dp.R ? 2 * dp.nacc : dp.R);
         auto flds = [&](int part) { return ((size_t)dp.R * dp.nz * UCF_WAVE + scols * part) * sizeof(lds_c); };
         int part = ucf_finish_part;
         if (part != 16 && part != 32 && part != 64) part = (flds(64) <= 40 * 1024) ? 64 : (flds(32) <= 40 * 1024) ? 32 : 16;
         const size_t fl = flds(part);
         if (fl > 160 * 1024) return UCF_ERR_UNSUPPORTED;
-#define UCF_LAUNCH_F(PART)                                                                                     \
+#define UCF_LAUNCH_F(PART, WR)                                                                                 \
     do {                                                                                                       \
         if (fl > 64 * 1024)                                                                                    \
-            (void)hipFuncSetAttribute((const void*)finish_kernel<LAYOUT, PART>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fl); \
-        hipLaunchKernelGGL((finish_kernel<LAYOUT, PART>), dim3((unsigned)nwork), block, fl, s, dp, nwork, per_point, nr, nsv, svmin, \
+            (void)hipFuncSetAttribute((const void*)finish_kernel<LAYOUT, PART, WR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fl); \
+        hipLaunchKernelGGL((finish_kernel<LAYOUT, PART, WR>), dim3((unsigned)nwork), block, fl, s, dp, nwork, per_point, nr, nsv, svmin, \
                            d_tD, d_rD, d_sv, d_h, d_dh, d_stats, nt, ir0, (double2*)d_totlap, (const double2*)d_state, \
                            (const int*)d_ndone);                                                               \
     } while (0)
-        if (part == 64) UCF_LAUNCH_F(64);
-        else if (part == 32) UCF_LAUNCH_F(32);
-        else UCF_LAUNCH_F(16);
+        if (wreg) { if (part == 64) UCF_LAUNCH_F(64, true); else if (part == 32) UCF_LAUNCH_F(32, true); else UCF_LAUNCH_F(16, true); }
+        else if (part == 64) UCF_LAUNCH_F(64, false);
+        else if (part == 32) UCF_LAUNCH_F(32, false);
+        else UCF_LAUNCH_F(16, false);
 #undef UCF_LAUNCH_F
         if (hipGetLastError() != hipSuccess) return UCF_ERR_HIP;
         // the unfinished ones (overflow regime): point_kernel over the list integrate_kernel left
