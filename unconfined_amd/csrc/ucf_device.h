@@ -511,6 +511,78 @@ UCF_DEV double dehoog_wave(cplx f, int M, double alpha, double logtol, double t,
     return exp(gamma * t) / tee * cdiv(A2M, B2M).re;                                            // :129
 }
 
+// dehoog_wave in two halves, for kernels that invert many vectors per wave (dehoog_tiles_kernel):
+//   dehoog_qd_wave   the quotient-difference rhombus (:80-101), cooperative as above; lane k keeps the
+//                    continued-fraction coefficient d(k) instead of every lane running the recurrence on broadcasts;
+//   dehoog_cf_lane   the A/B recurrence, improved remainder and scaling (:105-129) of ONE vector by ONE lane,
+//                    coefficients read from an LDS column -- 2T lanes finish 2T vectors at once.
+// Operation for operation the arithmetic of dehoog_wave: same bits.
+UCF_DEV cplx dehoog_qd_wave(cplx f, int M, int lane, ucf_stats* st, bool* zero)
+{
+    const int n2 = 2 * M;
+    const bool act = lane <= n2;
+    double mag = act ? cabs_(f) : 0.0;
+    if (d_isnan(mag)) mag = 0.0;                         // MAXVAL skips NaN operands
+    const double mx = wave_max(mag);
+    *zero = !(mx > UCF_DBL_MIN);                         // :69,139
+    if (*zero) {
+        if (st) stat_add(&st->zero_vectors, lane == 0);
+        return cmake(0.0, 0.0);
+    }
+    const bool nanp = act && (d_isnan(f.re) || d_isnan(f.im));
+    if (st) stat_add(&st->nan_scrubbed, nanp);
+    cplx ff = (nanp || !act) ? cmake(act ? 0.0 : 1.0, 0.0) : f;                                 // :71-74
+    const cplx ff0 = bcast0(ff);
+    const cplx d0 = cdivr(ff0, 2.0);                                                            // :98
+    cplx dmine = d0;                                     // lane 0 keeps d(0); the others are overwritten below
+    cplx fnext = shfl_down1(ff);
+    cplx q = (lane == 0) ? cdiv(fnext, d0) : cdiv(fnext, ff);                                   // :81-82  q(i,1)
+    if (lane > n2 - 1) q = cmake(1.0, 0.0);
+    cplx e = cmake(0.0, 0.0);                                                                   // :80     e(i,0)
+    for (int r = 1; r <= M; r++) {                                                              // :85-95
+        const cplx qn = shfl_down1(q);
+        const cplx en = shfl_down1(e);
+        cplx enew = cadd(csub(qn, q), en);
+        if (lane > 2 * (M - r)) enew = cmake(1.0, 0.0);      // outside the rhombus: keep lanes benign
+        const cplx dq = cneg(bcast0(q));                     // d(2r-1) = -q(0,r)                :100
+        const cplx de = cneg(bcast0(enew));                  // d(2r)   = -e(0,r)                :101
+        if (lane == 2 * r - 1) dmine = dq;
+        if (lane == 2 * r) dmine = de;
+        if (r < M) {
+            const cplx enn = shfl_down1(enew);
+            q = cdiv(cmul(qn, enn), enew);                                                      // :93
+            if (lane > 2 * (M - r - 1) + 1) q = cmake(1.0, 0.0);
+            e = enew;
+        }
+    }
+    return dmine;
+}
+
+UCF_DEV double dehoog_cf_lane(const lds_c* dcol, int pitch, int M, double alpha, double logtol, double t, double tee)
+{
+    const double gamma = alpha - logtol / (2.0 * tee);                                          // :77
+    const lds_c v0 = dcol[0];
+    const cplx d0 = cmake(v0.x, v0.y);
+    cplx Am2 = cmake(0.0, 0.0), Am1 = d0, Bm2 = cmake(1.0, 0.0), Bm1 = cmake(1.0, 0.0);         // :105-107
+    const cplx z = cexp_(cdivr(cscale(cscale(cmake(0.0, 1.0), UCF_PI), t), tee));               // :110
+    for (int n = 1; n <= 2 * M - 1; n++) {                                                      // :114-117
+        const lds_c v = dcol[(size_t)n * pitch];
+        const cplx d = cmake(v.x, v.y);
+        const cplx An = cadd(Am1, cmul(cmul(d, Am2), z));
+        const cplx Bn = cadd(Bm1, cmul(cmul(d, Bm2), z));
+        Am2 = Am1; Am1 = An; Bm2 = Bm1; Bm1 = Bn;
+    }
+    const lds_c vq = dcol[(size_t)(2 * M - 1) * pitch], ve = dcol[(size_t)(2 * M) * pitch];
+    const cplx dlast_q = cmake(vq.x, vq.y), dlast_e = cmake(ve.x, ve.y);
+    // :120-125 improved remainder
+    const cplx brem = cdivr(radd(1.0, cmul(csub(dlast_q, dlast_e), z)), 2.0);
+    const cplx inner = csqrt_(radd(1.0, cdiv(cmul(dlast_e, z), cmul(brem, brem))));
+    const cplx rem = cneg(cmul(brem, rsub(1.0, inner)));
+    const cplx A2M = cadd(Am1, cmul(rem, Am2));
+    const cplx B2M = cadd(Bm1, cmul(rem, Bm2));
+    return exp(gamma * t) / tee * cdiv(A2M, B2M).re;                                            // :129
+}
+
 // Same algorithm for 64 < 2M+1 <= 128: element i = lane + 64 g lives in register set g of its lane
 // (M up to 63).  Used by dehoog_points_kernel only; elementwise identical to dehoog_wave.
 UCF_DEV void shift_down_128(const cplx (&in)[2], cplx (&out)[2], int lane)
@@ -1207,18 +1279,23 @@ finish_kernel(const ucf_dev_params P, int npts, int per_point, int nr, int nsv, 
 // times); a wave takes a tile of UCF_DH_TILE consecutive times of one radius, transposes it through LDS
 // ([m][tile], rows padded to dodge bank conflicts) and inverts one time after the other with lane = m
 // (driver.f90:217-230).
-#define UCF_DH_TILE 16
+// For 2M+1 <= 64 the rhombus runs per vector (h and dh of each time) and leaves the continued-fraction
+// coefficients in LDS (h's in the column the input came from, dh's in a second tile); then 2 x UCF_DH_TILE lanes
+// each finish one vector.  The recurrence used to be uniform work repeated by all 64 lanes for every vector.
+#define UCF_DH_TILE 8
 __global__ void __launch_bounds__(UCF_WAVE)
 dehoog_tiles_kernel(const ucf_dev_params P, int nt, int nr, int ir0, int nrc, const double* __restrict__ tDv,
                     const double2* __restrict__ totlap, double* __restrict__ hout, double* __restrict__ dhout,
                     ucf_stats* st)
 {
-    extern __shared__ lds_c lds[];            // [np][UCF_DH_TILE + 1]
+    extern __shared__ lds_c lds[];            // [np][UCF_DH_TILE + 1] x 2, then 2 x UCF_DH_TILE flags
     const int lane = threadIdx.x;
     const int nz = P.nz, np = P.np;
     const int ntile = (nt + UCF_DH_TILE - 1) / UCF_DH_TILE;
     const long long nwork = (long long)nrc * ntile;
     const int pitch = UCF_DH_TILE + 1;
+    lds_c* tileB = lds + (size_t)np * pitch;
+    int* zflag = (int*)(tileB + (size_t)np * pitch);
     for (long long w = blockIdx.x; w < nwork; w += gridDim.x) {
         const int irl = (int)(w / ntile), it0 = (int)(w % ntile) * UCF_DH_TILE;
         const int ncur = (nt - it0 < UCF_DH_TILE) ? nt - it0 : UCF_DH_TILE;
@@ -1229,19 +1306,40 @@ dehoog_tiles_kernel(const ucf_dev_params P, int nt, int nr, int ir0, int nrc, co
                 if (tt < ncur) lds[m * pitch + tt] = src[(size_t)m * nt + it0 + tt];
             }
             __syncthreads();
-            for (int tt = 0; tt < ncur; tt++) {
-                const int it = it0 + tt;
-                const double tD = tDv[it];
-                const double tee = 2.0 * tD;
-                const double sigma = P.alpha - P.logtol / (2.0 * tee);
-                double hval, dval;
-                if (np <= UCF_WAVE) {
+            if (np <= UCF_WAVE) {
+                for (int tt = 0; tt < ncur; tt++) {
+                    const double tD = tDv[it0 + tt];
+                    const double tee = 2.0 * tD;
+                    const double sigma = P.alpha - P.logtol / (2.0 * tee);
                     cplx tl = cmake(0.0, 0.0);
                     if (lane < np) { const lds_c v = lds[lane * pitch + tt]; tl = cmake(v.x, v.y); }
                     const cplx p = cmake(sigma, UCF_PI * lane / tee);
-                    hval = dehoog_wave(tl, P.M, P.alpha, P.logtol, tD, tee, lane, st);
-                    dval = dehoog_wave(cmul(tl, p), P.M, P.alpha, P.logtol, tD, tee, lane, st) * tD;
-                } else {
+                    bool z0, z1;
+                    const cplx dh_ = dehoog_qd_wave(tl, P.M, lane, st, &z0);
+                    const cplx dd_ = dehoog_qd_wave(cmul(tl, p), P.M, lane, st, &z1);
+                    if (lane < np) {
+                        lds[lane * pitch + tt] = make_double2(dh_.re, dh_.im);
+                        tileB[lane * pitch + tt] = make_double2(dd_.re, dd_.im);
+                    }
+                    if (lane == 0) { zflag[2 * tt] = z0; zflag[2 * tt + 1] = z1; }
+                }
+                __syncthreads();
+                if (lane < 2 * ncur) {
+                    const int tt = lane >> 1, which = lane & 1;
+                    const int it = it0 + tt;
+                    const double tD = tDv[it];
+                    double val = 0.0;
+                    if (!zflag[lane]) val = dehoog_cf_lane((which ? tileB : lds) + tt, pitch, P.M, P.alpha, P.logtol, tD, 2.0 * tD);
+                    const size_t o = ((size_t)it * nr + ir0 + irl) * P.nz_out + P.z_off + z;
+                    if (which) dhout[o] = val * tD;
+                    else hout[o] = val;
+                }
+            } else {
+                for (int tt = 0; tt < ncur; tt++) {
+                    const int it = it0 + tt;
+                    const double tD = tDv[it];
+                    const double tee = 2.0 * tD;
+                    const double sigma = P.alpha - P.logtol / (2.0 * tee);
                     cplx tl[2], tp[2];
 #pragma unroll
                     for (int g = 0; g < 2; g++) {
@@ -1250,13 +1348,13 @@ dehoog_tiles_kernel(const ucf_dev_params P, int nt, int nr, int ir0, int nrc, co
                         if (i < np) { const lds_c v = lds[i * pitch + tt]; tl[g] = cmake(v.x, v.y); }
                         tp[g] = cmul(tl[g], cmake(sigma, UCF_PI * i / tee));
                     }
-                    hval = dehoog_wave2(tl, P.M, P.alpha, P.logtol, tD, tee, lane, st);
-                    dval = dehoog_wave2(tp, P.M, P.alpha, P.logtol, tD, tee, lane, st) * tD;
-                }
-                if (lane == 0) {
-                    const size_t o = ((size_t)it * nr + ir0 + irl) * P.nz_out + P.z_off + z;
-                    hout[o] = hval;
-                    dhout[o] = dval;
+                    const double hval = dehoog_wave2(tl, P.M, P.alpha, P.logtol, tD, tee, lane, st);
+                    const double dval = dehoog_wave2(tp, P.M, P.alpha, P.logtol, tD, tee, lane, st) * tD;
+                    if (lane == 0) {
+                        const size_t o = ((size_t)it * nr + ir0 + irl) * P.nz_out + P.z_off + z;
+                        hout[o] = hval;
+                        dhout[o] = dval;
+                    }
                 }
             }
             __syncthreads();
@@ -1637,7 +1735,7 @@ int launch_grid_transposed(const ucf_dev_params& dp, int nt, int nr, int ir0, in
                                  d_totlap, d_glscr, d_state, d_ndone, stream, ev0, ev1);
     if (rc) return rc;
     const long long ntl = (long long)nrc * ((nt + UCF_DH_TILE - 1) / UCF_DH_TILE);
-    const size_t dlds = (size_t)dp.np * (UCF_DH_TILE + 1) * sizeof(lds_c);
+    const size_t dlds = 2 * (size_t)dp.np * (UCF_DH_TILE + 1) * sizeof(lds_c) + 2 * UCF_DH_TILE * sizeof(int);
     hipLaunchKernelGGL(dehoog_tiles_kernel, dim3((unsigned)(ntl > 0x7fffffffLL ? 0x7fffffff : ntl)), dim3(UCF_WAVE), dlds, s, dp, nt, nr, ir0,
                        nrc, d_tD, (const double2*)d_totlap, d_h, d_dh, d_stats);
     return hipGetLastError() == hipSuccess ? UCF_OK : UCF_ERR_HIP;
