@@ -588,7 +588,7 @@ int ensure_glscr(ucf_plan* pl, int nz)
 // state of `items` work items between integrate_kernel and point_kernel (fast flavour, Hantush-based models)
 size_t state_item_bytes(const ucf_plan* pl, const ucf_dev_params& dp)
 {
-    return (pl->mode == 1) ? ucf_fast::state_bytes_per_item(dp) : 0;   // the faithful flavour integrates in point_kernel
+    return (pl->mode == 1) ? ucf_fast::state_bytes_per_item(dp) : ucf_faithful::state_bytes_per_item(dp);
 }
 int ensure_state(ucf_plan* pl, const ucf_dev_params& dp, size_t items)
 {
@@ -654,11 +654,11 @@ int launch_points_any(ucf_plan* pl, const ucf_dev_params& dp, int npts, int per_
         if (chunked) {
             rc = (pl->mode == 1)
                      ? ucf_fast::launch_points_chunked(dp, n, per_point, nr, nsv, svmin, tD, rD, sv, tab, pl->d_totlap, h, dh, d_stats, stream, pl->d_glscr, pl->d_state, pl->d_ndone, d_params, ppp, (int)base)
-                     : ucf_faithful::launch_points_chunked(dp, n, per_point, nr, nsv, svmin, tD, rD, sv, tab, pl->d_totlap, h, dh, d_stats, stream, pl->d_glscr, nullptr, nullptr);
+                     : ucf_faithful::launch_points_chunked(dp, n, per_point, nr, nsv, svmin, tD, rD, sv, tab, pl->d_totlap, h, dh, d_stats, stream, pl->d_glscr, pl->d_state, pl->d_ndone);
         } else {
             rc = (pl->mode == 1)
                      ? ucf_fast::launch_points(dp, n, per_point, nr, nsv, svmin, tD, rD, sv, tab, h, dh, d_stats, stream, pl->d_glscr, pl->d_state, pl->d_ndone, d_params, ppp, (int)base)
-                     : ucf_faithful::launch_points(dp, n, per_point, nr, nsv, svmin, tD, rD, sv, tab, h, dh, d_stats, stream, pl->d_glscr, nullptr, nullptr);
+                     : ucf_faithful::launch_points(dp, n, per_point, nr, nsv, svmin, tD, rD, sv, tab, h, dh, d_stats, stream, pl->d_glscr, pl->d_state, pl->d_ndone);
         }
         if (rc == UCF_ERR_UNSUPPORTED) return fail(rc, "this model / size combination has no kernel (model %d, LDS limit)", dp.model);
         if (rc) return fail(rc, "kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
@@ -742,14 +742,14 @@ int grid_device_chunk(ucf_plan* pl, int nt, const double* d_tD, const int* d_sv,
             if (!pl->ev0) { hipEvent_t a, b; if (hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) { pl->ev0 = a; pl->ev1 = b; } }
             tev0 = pl->ev0; tev1 = pl->ev1;
             pl->ev_valid = (tev0 && tev1);
-            pl->last_kernel = (pl->mode == 1) ? (state_item_bytes(pl, dp) ? "ucf_fast::integrate_kernel<FAMILY, 1>" : "ucf_fast::point_kernel<FAMILY, 1>")
-                                              : "ucf_faithful::point_kernel<FAMILY, 1>";
+            pl->last_kernel = (pl->mode == 1) ? "ucf_fast::integrate[_generic]_kernel<FAMILY, 1>"
+                                              : (state_item_bytes(pl, dp) ? "ucf_faithful::integrate_generic_kernel<FAMILY, 1>" : "ucf_faithful::point_kernel<FAMILY, 1>");
         }
         for (int ir0 = 0; ir0 < nr; ir0 += nrc) {
             const int n = (nr - ir0 < nrc) ? nr - ir0 : nrc;
             rc = (pl->mode == 1)
                      ? ucf_fast::launch_grid_transposed(dp, nt, nr, ir0, n, svmin, d_tD, d_rD, pl->d_work, pl->d_totlap, d_h, d_dh, d_stats, stream, tev0, tev1, pl->d_glscr, pl->d_state, pl->d_ndone)
-                     : ucf_faithful::launch_grid_transposed(dp, nt, nr, ir0, n, svmin, d_tD, d_rD, pl->d_work, pl->d_totlap, d_h, d_dh, d_stats, stream, tev0, tev1, pl->d_glscr, nullptr, nullptr);
+                     : ucf_faithful::launch_grid_transposed(dp, nt, nr, ir0, n, svmin, d_tD, d_rD, pl->d_work, pl->d_totlap, d_h, d_dh, d_stats, stream, tev0, tev1, pl->d_glscr, pl->d_state, pl->d_ndone);
             if (rc == UCF_ERR_UNSUPPORTED) return fail(rc, "this model / size combination has no kernel (model %d, LDS limit)", dp.model);
             if (rc) return fail(rc, "kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
         }

@@ -1241,7 +1241,79 @@ integrate_kernel(const ucf_dev_params P0, int npts, int per_point, int nr, int n
     }
 }
 
-// ------------------------------------------------------------------ the finishing kernel (fast flavour)
+#endif   // UCF_FAST
+
+// ------------------------------------------------------------------ the integration kernel, generic evaluators
+// Same split for the reference-order evaluators (faithful flavour; models without a fast evaluator): the abscissa
+// loop alone, every abscissa (these evaluators reproduce the reference's Inf/NaN behaviour themselves, nothing is
+// left for point_kernel), state to HBM, finish_kernel does the tail.  The out-of-line libm calls keep it at
+// 3 waves/SIMD instead of the 2 of the monolithic point_kernel.
+template <int FAMILY, int LAYOUT>
+__global__ void __launch_bounds__(UCF_WAVE, 3)
+integrate_generic_kernel(const ucf_dev_params P, int npts, int per_point, int nr, int nsv, int svmin,
+                         const double* __restrict__ tDv, const double* __restrict__ rDv, const int* __restrict__ svv,
+                         const double2* __restrict__ tab, int nt, int ir0, double2* __restrict__ state, int* __restrict__ ndone)
+{
+    extern __shared__ lds_c lds[];
+    const int lane = threadIdx.x;
+    const int nz = P.nz, R = P.R, nacc = P.nacc, N = P.N, ngl = P.ngl;
+    const int nabs = N + nacc * ngl;
+    lds_c* accTS = lds;                                     // [R][nz]  level sums
+    lds_c* accCur = lds + (size_t)R * nz * UCF_WAVE;        // [nz]     area of the J0 interval being integrated
+    lds_c* fdbuf = accCur + (size_t)nz * UCF_WAVE;          // FAMILY 4, faithful: [2*order] Thomas sweep
+    bool need_lay1 = false;
+    for (int z = 0; z < nz; z++) need_lay1 |= (P.zLay[z] == 1);
+    for (int pt = blockIdx.x; pt < npts; pt += gridDim.x) {
+        const work_item W = decode_item<LAYOUT>(P, pt, lane, per_point, nr, nt, ir0);
+        const double tD = tDv[W.it], rD = rDv[W.ir];
+        const int sv = (LAYOUT == 1) ? svmin : svv[W.it];
+        const double2* __restrict__ row = tab + (size_t)(per_point ? W.pidx : (W.ir * nsv + (sv - svmin))) * nabs;
+        const double tee = 2.0 * tD;                                                            // driver.f90:106,217
+        const double sigma = P.alpha - P.logtol / (2.0 * tee);                                  // invlap.f90:165
+        const cplx p = cmake(sigma, UCF_PI * W.mlap / tee);                                     // invlap.f90:168
+        const cplx lt = lap_time(P, p);
+        const cplx lane_aux = (FAMILY == 5) ? hstorage_A0(P, p) : cmake(0.0, 0.0);
+        double2* __restrict__ sti = state + (size_t)pt * state_slots(P) * UCF_WAVE;
+        double2* __restrict__ areas = sti + (size_t)(R + 1) * nz * UCF_WAVE;
+        for (int s = 0; s < (R + 1) * nz; s++) lds_st(lds, s, lane, cmake(0.0, 0.0));
+        int m = 0, jj = 0;
+        for (int n = 0; n < nabs; n++) {
+            const double2 aa = row[n];
+            sample_common S;
+            sample_prepare<FAMILY>(P, aa.x, p, need_lay1, S, fdbuf, lane, lane_aux);
+            const bool ts = n < N;
+            for (int z = 0; z < nz; z++) {
+                const cplx val = cmul(rscale(aa.y, sample_z<FAMILY>(P, S, z)), lt);              // lhs.f90:118
+                if (ts) {
+                    const int n1 = n + 1;                                                       // driver.f90:150
+                    for (int j = 1; j <= R; j++) {
+                        const int sh = R - j;
+                        if ((n1 & ((1 << sh) - 1)) == 0) {
+                            const double w = P.ts_w[(size_t)(j - 1) * N + ((n1 >> sh) - 1)];
+                            const int slot = (j - 1) * nz + z;
+                            lds_st(accTS, slot, lane, cadd(lds_ld(accTS, slot, lane), rscale(w, val)));
+                        }
+                    }
+                } else {
+                    cplx acc = cadd(lds_ld(accCur, z, lane), cscale(val, P.gl_w[m]));           // :201-202
+                    if (m == ngl - 1) {
+                        const double lob = P.j0z[sv + jj - 1] / rD;
+                        const double hib = P.j0z[sv + jj] / rD;
+                        acc = rscale((hib - lob) / 2.0, acc);
+                        areas[(size_t)(jj * nz + z) * UCF_WAVE + lane] = make_double2(acc.re, acc.im);
+                        acc = cmake(0.0, 0.0);
+                    }
+                    lds_st(accCur, z, lane, acc);
+                }
+            }
+            if (!ts && ++m == ngl) { m = 0; jj++; }
+        }
+        for (int s = 0; s < (R + 1) * nz; s++) sti[(size_t)s * UCF_WAVE + lane] = lds[s * UCF_WAVE + lane];
+        if (lane == 0) ndone[pt] = nabs;
+    }
+}
+
+// ------------------------------------------------------------------ the finishing kernel
 // Tail of every work item integrate_kernel completed (all of them outside the overflow regime): state ->
 // finish_item.  Model independent and small, so it runs at full occupancy; PART is chosen at launch from the
 // LDS footprint ((R+1) nz slots of level sums + max(2 nacc, R) scratch columns of PART lanes).
@@ -1273,7 +1345,6 @@ finish_kernel(const ucf_dev_params P, int npts, int per_point, int nr, int nsv, 
                                         totlap, hout, dhout);
     }
 }
-#endif
 
 // second half of LAYOUT 1: the transform arrives as [radius][z][m][time] (written coalesced by 64 consecutive
 // times); a wave takes a tile of UCF_DH_TILE consecutive times of one radius, transposes it through LDS
@@ -1571,24 +1642,27 @@ int launch_abscissae(const ucf_dev_params& dp, int nrows, int per_point, int nsv
 }
 #endif
 
-// does this flavour integrate in its own kernel (integrate_kernel -> point_kernel resuming from the state)?
-static inline bool split_integration(const ucf_dev_params& dp)
+// How the abscissa loop is run: 0 inside point_kernel; 1 integrate_kernel with the fast evaluators (fast flavour,
+// Hantush-based models), point_kernel resumes the items it leaves unfinished; 2 integrate_generic_kernel with the
+// reference-order evaluators (everything else, unless the finite-difference Thomas buffer makes the footprint huge)
+static inline int split_kind(const ucf_dev_params& dp)
 {
-#if UCF_FAST
     const int fam = family_of(dp);
-    return fam == 1 || fam == 2 || fam == 4;
+#if UCF_FAST
+    if (fam == 1 || fam == 2 || fam == 4) return 1;
 #else
-    return false;
+    if (fam == 4 && 2 * (size_t)dp.order * UCF_WAVE * sizeof(lds_c) > 16 * 1024) return 0;
 #endif
+    return 2;
 }
 // bytes of state per work item (0: no state needed)
 size_t state_bytes_per_item(const ucf_dev_params& dp)
 {
-    return split_integration(dp) ? (size_t)(dp.R + 1 + dp.nacc) * dp.nz * UCF_WAVE * sizeof(lds_c) : 0;
+    return split_kind(dp) ? (size_t)(dp.R + 1 + dp.nacc) * dp.nz * UCF_WAVE * sizeof(lds_c) : 0;
 }
 
-// The transform stage for `nwork` work items of lane layout LAYOUT: [integrate_kernel ->] point_kernel.
-// ev0/ev1 (optional) bracket the dominant kernel: integrate_kernel when the flavour has one, else point_kernel.
+// The transform stage for `nwork` work items of lane layout LAYOUT: [integrate kernel -> finish_kernel ->] point_kernel.
+// ev0/ev1 (optional) bracket the dominant kernel: the integrate kernel when there is one, else point_kernel.
 template <int LAYOUT, bool MULTI>
 static int launch_transform_(const ucf_dev_params& dp, int nwork, int per_point, int nr, int nsv, int svmin, const double* d_tD,
                             const double* d_rD, const int* d_sv, const double* d_tab, double* d_h, double* d_dh,
@@ -1599,7 +1673,8 @@ static int launch_transform_(const ucf_dev_params& dp, int nwork, int per_point,
     int* d_todo = d_ndone ? d_ndone + nwork : nullptr;     // [count | items]: the caller sizes d_ndone for 2 nwork + 1 ints
     const int fam = family_of(dp);
     if (fam < 0) return UCF_ERR_UNSUPPORTED;
-    const bool split = split_integration(dp);
+    const int kind = split_kind(dp);
+    const bool split = kind != 0;
     if (split && (!d_state || !d_ndone)) return UCF_ERR_BAD_ARGUMENT;
     const size_t lds = point_lds_bytes(dp, split);
     if (lds > 160 * 1024) return UCF_ERR_UNSUPPORTED;
@@ -1608,11 +1683,13 @@ static int launch_transform_(const ucf_dev_params& dp, int nwork, int per_point,
     if (al) d_glscr = nullptr;
     if (!split) { d_state = nullptr; d_ndone = nullptr; d_todo = nullptr; }
     dim3 grid((unsigned)((al || nwork < UCF_GRID_SLOTS) ? nwork : UCF_GRID_SLOTS)), block(UCF_WAVE);
-#if UCF_FAST
     if (split) {
-        const size_t ilds = (size_t)(dp.R + 1) * dp.nz * UCF_WAVE * sizeof(lds_c);
         (void)hipMemsetAsync(d_todo, 0, sizeof(int), s);
         if (ev0) (void)hipEventRecord((hipEvent_t)ev0, s);
+    }
+#if UCF_FAST
+    if (kind == 1) {
+        const size_t ilds = (size_t)(dp.R + 1) * dp.nz * UCF_WAVE * sizeof(lds_c);
 #define UCF_LAUNCH_I(F, W, FO)                                                                                 \
     do {                                                                                                       \
         if (ilds > 64 * 1024)                                                                                  \
@@ -1636,6 +1713,34 @@ static int launch_transform_(const ucf_dev_params& dp, int nwork, int per_point,
         case 4: if (fold) UCF_LAUNCH_I(4, 4, true); else UCF_LAUNCH_I(4, 4, false); break;
         }
 #undef UCF_LAUNCH_I
+    }
+#endif
+    if (kind == 2) {
+        if (MULTI) return UCF_ERR_UNSUPPORTED;
+        size_t ilds = (size_t)(dp.R + 1) * dp.nz * UCF_WAVE * sizeof(lds_c);
+#if !UCF_FAST
+        if (fam == 4) ilds += 2 * (size_t)dp.order * UCF_WAVE * sizeof(lds_c);
+#endif
+#define UCF_LAUNCH_G(F)                                                                                        \
+    do {                                                                                                       \
+        if (ilds > 64 * 1024)                                                                                  \
+            (void)hipFuncSetAttribute((const void*)integrate_generic_kernel<F, LAYOUT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ilds); \
+        hipLaunchKernelGGL((integrate_generic_kernel<F, LAYOUT>), dim3((unsigned)nwork), block, ilds, s, dp, nwork, per_point, nr, nsv, svmin, \
+                           d_tD, d_rD, d_sv, (const double2*)d_tab, nt, ir0, (double2*)d_state, d_ndone);      \
+    } while (0)
+        switch (fam) {
+        case 0: UCF_LAUNCH_G(0); break;
+        case 3: UCF_LAUNCH_G(3); break;
+        case 5: UCF_LAUNCH_G(5); break;
+#if !UCF_FAST                   /* the fast flavour has integrate_kernel for these */
+        case 1: UCF_LAUNCH_G(1); break;
+        case 2: UCF_LAUNCH_G(2); break;
+        case 4: UCF_LAUNCH_G(4); break;
+#endif
+        }
+#undef UCF_LAUNCH_G
+    }
+    if (split) {
         if (ev1) (void)hipEventRecord((hipEvent_t)ev1, s);
         if (hipGetLastError() != hipSuccess) return UCF_ERR_HIP;
         ev0 = ev1 = nullptr;
@@ -1663,10 +1768,10 @@ static int launch_transform_(const ucf_dev_params& dp, int nwork, int per_point,
         else UCF_LAUNCH_F(16, false);
 #undef UCF_LAUNCH_F
         if (hipGetLastError() != hipSuccess) return UCF_ERR_HIP;
+        if (kind == 2) return UCF_OK;              // the generic evaluators leave nothing unfinished
         // the unfinished ones (overflow regime): point_kernel over the list integrate_kernel left
         grid = dim3((unsigned)(nwork < 2048 ? nwork : 2048));
     }
-#endif
     if (ev0) (void)hipEventRecord((hipEvent_t)ev0, s);
 #define UCF_LAUNCH(F)                                                                                          \
     do {                                                                                                       \

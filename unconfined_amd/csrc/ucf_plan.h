@@ -99,6 +99,7 @@ int launch_grid_transposed(const ucf_dev_params& dp, int nt, int nr, int ir0, in
 int launch_samples(const ucf_dev_params& dp, int n_a, const double* d_a, double rD, const double* d_p, double* d_fp,
                    void* stream);
 int launch_bessel(int n, const double* d_z, double* d_k, int* d_ierr, void* stream);
+size_t state_bytes_per_item(const ucf_dev_params& dp);
 int launch_dehoog(int n, int M, double alpha, double logtol, const double* d_t, const double* d_tee,
                   const double* d_fp, double* d_ft, void* stream);
 int launch_wynn(int n, int nterms, const double* d_series, double* d_acc, int* d_status, void* stream);
