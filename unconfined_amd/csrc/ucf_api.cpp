@@ -195,12 +195,26 @@ void gauss_lobatto(int ord, double* xo, double* wo)
     }
 }
 
-// depths per launch: as many as keep the wave's LDS footprint <= 40 KB (>= 4 workgroups per CU), at most UCF_MAX_NZ
+// depths per launch.  The integrate kernels keep (R+1) KB of accumulators per depth in LDS and share the
+// z-independent half of every sample among the depths of a launch: ~12 KB (2 depths at R = 4) balances occupancy
+// against that sharing (measured: 21 depths of the C2 settings take 54 / 44 / 49 / 51 / 66 ms at 1 / 2 / 3 / 4 / 7
+// depths per launch).  The monolithic point_kernel (faithful finite-difference closure) takes as many as keep its
+// footprint <= 40 KB.  At most UCF_MAX_NZ; UCF_Z_CHUNK overrides (diagnostic).
 int z_chunk(const ucf_plan* plan)
 {
     const int R = plan->P.R, nacc = plan->P.nacc;
-    const size_t scr = (size_t)(2 * nacc > R ? 2 * nacc : R) * 16 * 16;
-    int n = (int)(((size_t)40 * 1024 - scr) / ((size_t)(R + 1) * UCF_WAVE * 16));
+    ucf_dev_params one = plan->dev;
+    one.nz = 1;
+    const bool split = (plan->mode == 1 ? ucf_fast::state_bytes_per_item(one) : ucf_faithful::state_bytes_per_item(one)) != 0;
+    int n;
+    if (split) {
+        n = (int)(((size_t)12 * 1024) / ((size_t)(R + 1) * UCF_WAVE * 16));
+    } else {
+        const size_t scr = (size_t)(2 * nacc > R ? 2 * nacc : R) * 16 * 16;
+        n = (int)(((size_t)40 * 1024 - scr) / ((size_t)(R + 1) * UCF_WAVE * 16));
+    }
+    static const int forced = [] { const char* e = std::getenv("UCF_Z_CHUNK"); return e ? std::atoi(e) : 0; }();
+    if (forced > 0) n = forced;
     if (n < 1) n = 1;
     if (n > UCF_MAX_NZ) n = UCF_MAX_NZ;
     return n;
