@@ -366,6 +366,12 @@ def test_edge_cases(engine, oracle, oracle_quad):
     assert np.array_equal(hbq.reshape(2, 3, 23), hm)
     hoq, doq = oracle.batch(P, TTq.ravel(), RRq.ravel(), np.ones(6, np.int32), zmany, zlm)
     assert rel_err(hbq, hoq, 1e-6).max() < 1e-7
+    # a depth outside the aquifer (zD > 1): not physical, but the reference evaluates it; the fast flavour hands
+    # such calls to the generic evaluator
+    zo = np.array([0.5, 1.2]); zlo = plan.zlay(zo)
+    hx, dhx = plan.drawdown(tD[:4], np.full(4, 0.4), sv[:4], zo, zlo)
+    hox, dhox = oracle.batch(P, tD[:4], np.full(4, 0.4), sv[:4], zo, zlo)
+    assert rel_err(hx, hox, 1e-6).max() < 1e-4          # (ill-conditioned there: the reference's own values reach 1e15)
     # Laplace sample counts around the wave width: 2M+1 = 63 (one per lane), 65 and 127 (two per lane)
     tDm = np.array([0.05, 1.0, 40.0]); rDm = np.array([0.5, 0.5, 0.5]); svm = np.ones(3, np.int32)
     for M in (31, 32, 63):

@@ -257,6 +257,10 @@ int fill_call_params(const ucf_plan* plan, int nz, const double* zD, const int* 
         dp.fast_eta_max = 700.0 / cprod;
         if (dp.model == 6 && dp.MNtype == 2 && dp.fast_eta_max > 350.0) dp.fast_eta_max = 350.0;   // FD closure: cosh(eta)/h^2 terms
     }
+    // depths outside the aquifer (the reference evaluates them all the same: growing exponentials): the fast
+    // evaluators assume 0 <= zD <= 1, so the generic evaluator takes every abscissa of such a call
+    for (int i = 0; i < nz; i++)
+        if (!(zD[i] >= 0.0 && zD[i] <= 1.0)) dp.fast_eta_max = -1.0;
     static const double eta_cap = [] { const char* e = std::getenv("UCF_FAST_ETA_MAX"); return e ? std::atof(e) : 0.0; }();
     if (eta_cap > 0.0 && dp.fast_eta_max > eta_cap) dp.fast_eta_max = eta_cap;      // diagnostic: hand more of the range to the generic evaluator
     return UCF_OK;
