@@ -371,7 +371,9 @@ def test_edge_cases(engine, oracle, oracle_quad):
     zo = np.array([0.5, 1.2]); zlo = plan.zlay(zo)
     hx, dhx = plan.drawdown(tD[:4], np.full(4, 0.4), sv[:4], zo, zlo)
     hox, dhox = oracle.batch(P, tD[:4], np.full(4, 0.4), sv[:4], zo, zlo)
-    assert rel_err(hx, hox, 1e-6).max() < 1e-4          # (ill-conditioned there: the reference's own values reach 1e15)
+    assert np.array_equal(np.isnan(hx), np.isnan(hox))
+    assert rel_err(hx[:, 0], hox[:, 0], 1e-6).max() < 1e-7      # the depth inside the aquifer; the other one is
+    # ill-conditioned beyond comparison (the reference's own values reach 1e15 there)
     # Laplace sample counts around the wave width: 2M+1 = 63 (one per lane), 65 and 127 (two per lane)
     tDm = np.array([0.05, 1.0, 40.0]); rDm = np.array([0.5, 0.5, 0.5]); svm = np.ones(3, np.int32)
     for M in (31, 32, 63):
