@@ -470,6 +470,26 @@ def test_parameter_batched_sweep(engine):
             assert np.array_equal(hg[k], h1 * D.Hc, equal_nan=True) and np.array_equal(dhg[k], dh1 * D.Hc, equal_nan=True), k
 
 
+def test_random_parameter_sets_fast_vs_faithful():
+    """a broad net over the parameter space (models 1, 3, 4, 5, 6-FD; full and partial penetration, all three
+    layers, kappa over two decades, radii down to the overflow regime): the two flavours agree to 1e-7 of the
+    solution's scale, and where they do not, the reference itself is that far from exact arithmetic (cancellation above
+    the screen at large eta, Inf/NaN regime): the fast flavour must then be no further from the binary128
+    evaluation than 30x the reference's own distance"""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_flavours
+    worst, judged = fuzz_flavours.run(nsets=40, seed=11, verbose=False, judge_above=1e-7, max_judged=12)
+    assert len(worst) >= 30
+    assert all(w[-1] for w in worst), "NaN patterns differ"
+    arb = {j[0]: j for j in judged}
+    for w in worst:
+        if w[0] > 1e-7:
+            assert w[1] in arb, w
+            _, e_fast, e_faithful, e_ref = arb[w[1]]
+            assert e_fast <= 30.0 * max(e_ref, 1e-10), (w, arb[w[1]])
+
+
 def test_smoke_entry():
     import __graft_entry__ as g
     g.smoke()
