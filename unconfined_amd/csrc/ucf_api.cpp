@@ -943,13 +943,8 @@ int ucf_drawdown_multi(ucf_plan* const* plans, int nplans, int npts, const doubl
     if (one_launch) {
         ucf_plan* pl = plans[0];
         std::vector<ucf_dev_params> dps(nplans);
-        for (int k = 0; k < nplans; k++) {
-            int rc = fill_call_params(plans[k], nz, &zD[(size_t)k * nz], &zl[(size_t)k * nz], dps[k]);
-            if (rc) return rc;
-        }
         dev_buf b_p;
         if (b_p.alloc(sizeof(ucf_dev_params) * nplans)) return fail(UCF_ERR_NOMEM, "device allocation failed for %d parameter blocks", nplans);
-        HIP_TRY(hipMemcpy(b_p.p, dps.data(), sizeof(ucf_dev_params) * nplans, hipMemcpyHostToDevice));
         // one abscissa row per (plan, point), in chunks that keep the table <= 256 MiB
         const size_t row_bytes = (size_t)pl->D.nabs * 2 * sizeof(double);
         size_t chunk = ((size_t)256 << 20) / row_bytes;
@@ -957,16 +952,27 @@ int ucf_drawdown_multi(ucf_plan* const* plans, int nplans, int npts, const doubl
         if (chunk > tot) chunk = tot;
         int rc = ensure_work(pl, chunk * row_bytes);
         if (rc) return rc;
-        for (size_t base = 0; base < tot && rc == UCF_OK; base += chunk) {
-            const int n = (int)((tot - base < chunk) ? tot - base : chunk);
-            rc = ucf_faithful::launch_abscissae(dps[0], n, 1, 1, 0, (const double*)b_r.p + base, (const int*)b_s.p + base, pl->d_work, nullptr);
-            if (rc) return fail(rc, "abscissa kernel launch failed");
-            // points [base, base + n) of the flattened (plan, point) index; plan of point q = q / npts
-            rc = launch_points_any(pl, dps[0], n, 1, 1, 1, 0, (const double*)b_t.p + base, (const double*)b_r.p + base,
-                                   (const int*)b_s.p + base, (double*)b_h.p + base * nz, (double*)b_d.p + base * nz, nullptr, nullptr,
-                                   (const ucf_dev_params*)b_p.p + 0, npts);
-            if (rc) return rc;
-            if (base + chunk < tot) HIP_TRY(hipDeviceSynchronize());      // the next chunk rewrites the table
+        // depths in the same chunks as every other entry point (LDS budget of the integrate kernels)
+        const int zc = z_chunk(pl);
+        for (int z0 = 0; z0 < nz && rc == UCF_OK; z0 += zc) {
+            const int nzc = (nz - z0 < zc) ? nz - z0 : zc;
+            for (int k = 0; k < nplans; k++) {
+                rc = fill_call_params(plans[k], nzc, &zD[(size_t)k * nz + z0], &zl[(size_t)k * nz + z0], dps[k], nz, z0);
+                if (rc) return rc;
+            }
+            HIP_TRY(hipDeviceSynchronize());                              // the previous chunk still reads the parameter blocks
+            HIP_TRY(hipMemcpy(b_p.p, dps.data(), sizeof(ucf_dev_params) * nplans, hipMemcpyHostToDevice));
+            for (size_t base = 0; base < tot && rc == UCF_OK; base += chunk) {
+                const int n = (int)((tot - base < chunk) ? tot - base : chunk);
+                rc = ucf_faithful::launch_abscissae(dps[0], n, 1, 1, 0, (const double*)b_r.p + base, (const int*)b_s.p + base, pl->d_work, nullptr);
+                if (rc) return fail(rc, "abscissa kernel launch failed");
+                // points [base, base + n) of the flattened (plan, point) index; plan of point q = q / npts
+                rc = launch_points_any(pl, dps[0], n, 1, 1, 1, 0, (const double*)b_t.p + base, (const double*)b_r.p + base,
+                                       (const int*)b_s.p + base, (double*)b_h.p + base * nz, (double*)b_d.p + base * nz, nullptr, nullptr,
+                                       (const ucf_dev_params*)b_p.p + 0, npts);
+                if (rc) return rc;
+                if (base + chunk < tot) HIP_TRY(hipDeviceSynchronize());      // the next chunk rewrites the table
+            }
         }
         HIP_TRY(hipDeviceSynchronize());
         HIP_TRY(hipMemcpy(h, b_h.p, sizeof(double) * tot * nz, hipMemcpyDeviceToHost));

@@ -1168,8 +1168,8 @@ integrate_kernel(const ucf_dev_params P0, int npts, int per_point, int nr, int n
     for (int pt = blockIdx.x; pt < npts; pt += gridDim.x) {
         const work_item W = decode_item<LAYOUT>(P0, pt, lane, per_point, nr, nt, ir0);
         const ucf_dev_params& P = item_params<MULTI>(P0, Pv, W.pidx + pbase, ppp);
-        bool need_lay1 = false;
-        for (int z = 0; z < nz; z++) need_lay1 |= (P.zLay[z] == 1);
+        bool need_lay1 = false, need_lay3 = false, need_lay12 = false;
+        for (int z = 0; z < nz; z++) { need_lay1 |= (P.zLay[z] == 1); need_lay3 |= (P.zLay[z] == 3); need_lay12 |= (P.zLay[z] != 3); }
         const double tD = tDv[W.it], rD = rDv[W.ir];
         const int sv = (LAYOUT == 1) ? svmin : svv[W.it];
         const double2* __restrict__ row = tab + (size_t)(per_point ? W.pidx : (W.ir * nsv + (sv - svmin))) * nabs;
@@ -1195,7 +1195,7 @@ integrate_kernel(const ucf_dev_params P0, int npts, int per_point, int nr, int n
             const bool ts = n < N;
             const double w = ts ? 0.0 : P.gl_w[m];
             if (!__all(fast_eta<FAMILY>(P, LC, aa.x, F))) break;
-            fast_common_terms<FAMILY, FOLD>(P, LC, aa.x, need_lay1, F);
+            fast_common_terms<FAMILY, FOLD>(P, LC, aa.x, need_lay1, F, need_lay3, need_lay12);
             const int n1 = n + 1;
             int tz = __builtin_ctz(n1);
             if (tz > R - 1) tz = R - 1;

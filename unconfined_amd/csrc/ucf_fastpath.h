@@ -156,7 +156,8 @@ struct fast_common {
     fprim p1;            // primitive of eta itself (valid when have_p1)
     bool have_p1;
     cplx fd_s1;          // FD: sigma(1)
-    bool small_eta, fd_use;
+    cplx top3, fd_s13;   // the same two for depths above the screen top (cancellation-free water-table value)
+    bool small_eta, fd_use, fd_use3;
     bool any_small, any_large;   // wave-uniform: some lane on the cosh/sinh form, some lane on the exponential form
 };
 
@@ -186,12 +187,14 @@ UCF_DEV bool fast_eta(const ucf_dev_params& P, const lane_consts& L, double a, f
 // FOLD: the plan is known to be fully penetrating (fold_dD and fold_lD1), so that none of the screen terms is even
 // compiled in (the launcher picks the instantiation; FOLD = false handles every plan)
 template <int FAMILY, bool FOLD = false>
-UCF_DEV void fast_common_terms(const ucf_dev_params& P, const lane_consts& L, double a, bool need_lay1_in, fast_common& S)
+UCF_DEV void fast_common_terms(const ucf_dev_params& P, const lane_consts& L, double a, bool need_lay1_in, fast_common& S,
+                               bool need_lay3_in = false, bool need_lay12 = true)
 {
     const double a2 = a * a;
     const bool hantush = !(FAMILY == 2 && P.model == 4);
     const bool z1 = FOLD || P.fold_dD != 0, z2 = FOLD || P.fold_lD1 != 0;
     const bool need_lay1 = FOLD ? false : need_lay1_in;           // a fully penetrating screen has no layer below it
+    const bool need_lay3 = FOLD ? false : need_lay3_in;           // ... nor above it
     // the water-table closure switches to its exponential form at Re(eta) >= maxexp (:84) and then needs neither
     // cosh(eta) nor sinh(eta): decide per wave what has to be evaluated at all
     S.small_eta = (FAMILY != 2) || (S.eta.re < P.maxexp);                                       // :84
@@ -199,8 +202,9 @@ UCF_DEV void fast_common_terms(const ucf_dev_params& P, const lane_consts& L, do
     S.any_large = (FAMILY == 2) && (__builtin_amdgcn_ballot_w64(!S.small_eta) != 0);
     const bool need_p1 = (hantush && (!(z1 && z2) || need_lay1)) || FAMILY == 4 || (FAMILY == 2 && S.any_small);
     S.have_p1 = need_p1 && !z2;      // kept only where fast_hantush_z derives the primitive of eta (1 - zD) from it
+    fprim p1;
     if (need_p1) {
-        const fprim p1 = prim(S.eta.re, S.eta.im);
+        p1 = prim(S.eta.re, S.eta.im);
         if (!z2) S.p1 = p1;
         S.che = pcosh(p1);
         S.she = psinh(p1);
@@ -222,16 +226,38 @@ UCF_DEV void fast_common_terms(const ucf_dev_params& P, const lane_consts& L, do
         }
         if (FAMILY != 1) {
             // water-table value: hantush at zD = 1 (layer 3): g1 - g2                          (:81,162-170,196)
-            cplx g1;
-            if (z1) g1 = cmake(1.0, 0.0);
-            else if (P.share_g1top) g1 = pcosh(pd);
-            else { const double c = P.dD1 - 1.0; g1 = pcosh(prim(S.eta.re * c, S.eta.im * c)); }
-            cplx udp = g1;
-            if (!(z1 && z2)) udp = csub(g1, cmul(cadd(cmul(S.ff1, S.che), S.ff2), S.inv_she));
-            S.top = cscale(cmul(udp, S.th), P.inv_bD);                                          // :200
+            S.top = S.top3 = cscale(S.th, P.inv_bD);
+            if (!(z1 && z2)) {
+                if (need_lay12) {
+                    cplx g1;
+                    if (z1) g1 = cmake(1.0, 0.0);
+                    else if (P.share_g1top) g1 = pcosh(pd);
+                    else { const double c = P.dD1 - 1.0; g1 = pcosh(prim(S.eta.re * c, S.eta.im * c)); }
+                    const cplx udp = csub(g1, cmul(cadd(cmul(S.ff1, S.che), S.ff2), S.inv_she));
+                    S.top = cscale(cmul(udp, S.th), P.inv_bD);                                  // :200
+                }
+                if (need_lay3) {
+                    // For a depth above the screen top the rounding noise of that form matters (two terms of size
+                    // e^{eta dD} leave one of size e^{-eta dD}, and the depth's own factor e^{eta (zD - 1)} no
+                    // longer damps it).  Equivalent without the cancellation, used for those depths only:
+                    //   g1 - g2 = cosh(eta dD) - [sinh(eta dD) cosh(eta) + sinh(eta lD1)] / sinh(eta)
+                    //           = [sinh(eta (1 - dD)) - sinh(eta lD1)] / sinh(eta)
+                    cplx sd1 = S.she;
+                    if (!z1) {
+                        // sinh(eta (1 - dD)) from the primitives of eta and eta dD (exponentials divide, angles
+                        // subtract): accurate in the absolute sense only, good for a sinh of modulus >~ 1; the few
+                        // abscissae with a small eta (1 - dD) get their own primitive
+                        const double x1 = S.eta.re * P.dD1;
+                        if (__builtin_amdgcn_ballot_w64(!(x1 >= 1.0)) == 0) sd1 = psinh(prim_difference(p1, pd));
+                        else sd1 = psinh(prim(x1, S.eta.im * P.dD1));
+                    }
+                    const cplx udp = cmul(z2 ? sd1 : csub(sd1, S.ff2), S.inv_she);
+                    S.top3 = cscale(cmul(udp, S.th), P.inv_bD);
+                }
+            }
         }
     } else {
-        S.top = S.th;                                                                           // :78-79
+        S.top = S.top3 = S.th;                                                                  // :78-79
     }
     if (FAMILY == 2) {
         const cplx xi = cmul(S.eta, L.xifac);                                                   // :70-75
@@ -260,10 +286,18 @@ UCF_DEV void fast_common_terms(const ucf_dev_params& P, const lane_consts& L, do
         const cplx iB2 = cinv_plain(Bn);
         const cplx a2v = cscale(S.che, invhsq);                                                 // :508-509
         const cplx B1p = csub(b1, cmul(rscale(csup, a2v), iB2));
+        const cplx iB1p = cinv_scaled(B1p);
         const cplx v1 = cneg(cmul(cc, S.top)), v2 = rscale(-invhsq, S.top);                     // :513-514
         const cplx v1p = csub(v1, cmul(rscale(csup, iB2), v2));
-        S.fd_s1 = cmul(v1p, cinv_scaled(B1p));
+        S.fd_s1 = cmul(v1p, iB1p);
         S.fd_use = (fabs(S.fd_s1.re) + fabs(S.fd_s1.im)) > 2.3e-308;                            // :521
+        S.fd_s13 = S.fd_s1;
+        S.fd_use3 = S.fd_use;
+        if (need_lay3) {
+            const cplx w1 = cneg(cmul(cc, S.top3)), w2 = rscale(-invhsq, S.top3);
+            S.fd_s13 = cmul(csub(w1, cmul(rscale(csup, iB2), w2)), iB1p);
+            S.fd_use3 = (fabs(S.fd_s13.re) + fabs(S.fd_s13.im)) > 2.3e-308;
+        }
     }
 }
 
@@ -271,7 +305,9 @@ template <int FAMILY>
 UCF_DEV bool fast_prepare(const ucf_dev_params& P, const lane_consts& L, double a, bool need_lay1, fast_common& S)
 {
     if (!fast_eta<FAMILY>(P, L, a, S)) return false;
-    fast_common_terms<FAMILY>(P, L, a, need_lay1, S);
+    bool need_lay3 = false, need_lay12 = false;
+    for (int z = 0; z < P.nz; z++) { need_lay3 |= (P.zLay[z] == 3); need_lay12 |= (P.zLay[z] != 3); }
+    fast_common_terms<FAMILY>(P, L, a, need_lay1, S, need_lay3, need_lay12);
     return true;
 }
 
@@ -306,18 +342,25 @@ UCF_DEV cplx fast_hantush_z(const ucf_dev_params& P, const fast_common& S, doubl
             { const double c = 1.0 - zD; p1z = prim(S.eta.re * c, S.eta.im * c); }
         }
         if (!z2 && FAMILY == 2 && S.any_large) *exz_out = pexpneg(p1z);                         // exp(eta*(zD-1))
-        if (!(z1 && z2)) {
-            cplx num = cmake(0.0, 0.0);
-            if (!z1) num = cmul(S.ff1, chz);
-            if (!z2) num = cadd(num, cmul(S.ff2, pcosh(p1z)));
-            g2 = cmul(num, S.inv_she);                                                          // :179-180
-        }
+        cplx f2c = cmake(0.0, 0.0);
+        if (!z2) f2c = cmul(S.ff2, pcosh(p1z));                  // sinh(eta lD1) cosh(eta (1 - zD))
         if (lay == 2) {
             if (z1 && z2) return cscale(S.th, P.inv_bD);                                        // g2 = 0: udp = 1
+            cplx num = f2c;
+            if (!z1) num = cadd(cmul(S.ff1, chz), f2c);
+            g2 = cmul(num, S.inv_she);                                                          // :179-180
             udp = rsub(1.0, g2);                                                                // :192
         } else {
-            const double c = P.dD1 - zD;
-            udp = csub(pcosh(prim(S.eta.re * c, S.eta.im * c)), g2);                            // :175,196
+            // above the screen top: g1 - g2 = cosh(eta (dD1 - zD)) - g2 (:175,196) subtracts two terms of size
+            // e^{eta c}/2, c = zD - dD1 >= 0, that agree to e^{-2 eta c}.  With cosh A sinh B = [sinh(A+B) - sinh(A-B)]/2
+            // the large parts cancel analytically:
+            //   (g1 - g2) sinh(eta) = sinh(eta (2 - zD - dD))/2 + sinh(eta (zD - dD))/2 - sinh(eta lD1) cosh(eta (1 - zD))
+            const double ca = 2.0 - zD - P.dD, cb = zD - P.dD;
+            const cplx sa = psinh(prim(S.eta.re * ca, S.eta.im * ca));
+            const cplx sb = psinh(prim(S.eta.re * cb, S.eta.im * cb));
+            // (explicit FMAs: the same bits in every instantiation of the kernel)
+            const cplx num = cmake(__builtin_fma(0.5, sa.re + sb.re, -f2c.re), __builtin_fma(0.5, sa.im + sb.im, -f2c.im));
+            udp = cmul(num, S.inv_she);
         }
     }
     return cscale(cmul(udp, S.th), P.inv_bD);                                                   // :200
@@ -332,6 +375,7 @@ UCF_DEV cplx fast_sample_z(const ucf_dev_params& P, const fast_common& S, int iz
     if (FAMILY == 1) return fast_hantush_z<1, FOLD>(P, S, zD, lay, &chz, &exz);
     if (FAMILY == 4) {
         const cplx sH = fast_hantush_z<4, FOLD>(P, S, zD, lay, &chz, &exz);
+        if (!FOLD && lay == 3) return S.fd_use3 ? cadd(sH, cmul(S.fd_s13, chz)) : sH;
         return S.fd_use ? cadd(sH, cmul(S.fd_s1, chz)) : sH;                                    // :522-525
     }
     cplx u;
@@ -343,8 +387,9 @@ UCF_DEV cplx fast_sample_z(const ucf_dev_params& P, const fast_common& S, int iz
         u = fast_hantush_z<2, FOLD>(P, S, zD, lay, &chz, &exz);
         if (S.any_large && lay == 1) { const double c = 1.0 - zD; exz = expneg_direct(S.eta.re * c, S.eta.im * c); }
     }
-    if (S.small_eta) return csub(u, cmul(cmul(S.top, chz), S.inv_den));                         // :85-87
-    return csub(u, cmul(cmul(S.top, exz), S.inv_den));                                          // :89-91
+    const cplx top = (!FOLD && P.model != 4 && lay == 3) ? S.top3 : S.top;
+    if (S.small_eta) return csub(u, cmul(cmul(top, chz), S.inv_den));                           // :85-87
+    return csub(u, cmul(cmul(top, exz), S.inv_den));                                            // :89-91
 }
 
 }  // namespace UCF_NS
