@@ -1147,6 +1147,9 @@ point_kernel(const ucf_dev_params P0, int npts, int per_point, int nr, int nsv, 
 #ifndef UCF_FOLD_WAVES
 #define UCF_FOLD_WAVES 5
 #endif
+#ifndef UCF_UNFOLD_WAVES
+#define UCF_UNFOLD_WAVES 4
+#endif
 // WAVES per SIMD the register budget is cut for: 5 when the LDS footprint lets 20 waves share a CU (nz = 1), else 4
 template <int FAMILY, int LAYOUT, int WAVES, bool MULTI, bool FOLD>
 __global__ void __launch_bounds__(UCF_WAVE, WAVES)
@@ -1707,7 +1710,7 @@ static int launch_transform_(const ucf_dev_params& dp, int nwork, int per_point,
 #ifdef UCF_UNFOLDED_W5
             else { if (w5) UCF_LAUNCH_I(2, 5, false); else UCF_LAUNCH_I(2, 4, false); }
 #else
-            else UCF_LAUNCH_I(2, 4, false);        // the screen terms need the registers: 5 waves/SIMD would spill ~50 VGPRs
+            else UCF_LAUNCH_I(2, UCF_UNFOLD_WAVES, false);   // the screen terms need the registers: 5 waves/SIMD would spill ~50 VGPRs
 #endif
             break;
         case 4: if (fold) UCF_LAUNCH_I(4, 4, true); else UCF_LAUNCH_I(4, 4, false); break;
