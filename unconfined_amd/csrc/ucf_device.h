@@ -1151,7 +1151,7 @@ point_kernel(const ucf_dev_params P0, int npts, int per_point, int nr, int nsv, 
 #define UCF_UNFOLD_WAVES 4
 #endif
 // WAVES per SIMD the register budget is cut for: 5 when the LDS footprint lets 20 waves share a CU (nz = 1), else 4
-template <int FAMILY, int LAYOUT, int WAVES, bool MULTI, bool FOLD>
+template <int FAMILY, int LAYOUT, int WAVES, bool MULTI, bool FOLD, bool LAY3>
 __global__ void __launch_bounds__(UCF_WAVE, WAVES)
 integrate_kernel(const ucf_dev_params P0, int npts, int per_point, int nr, int nsv, int svmin,
                  const double* __restrict__ tDv, const double* __restrict__ rDv, const int* __restrict__ svv,
@@ -1198,13 +1198,13 @@ integrate_kernel(const ucf_dev_params P0, int npts, int per_point, int nr, int n
             const bool ts = n < N;
             const double w = ts ? 0.0 : P.gl_w[m];
             if (!__all(fast_eta<FAMILY>(P, LC, aa.x, F))) break;
-            fast_common_terms<FAMILY, FOLD>(P, LC, aa.x, need_lay1, F, need_lay3, need_lay12);
+            fast_common_terms<FAMILY, FOLD, LAY3>(P, LC, aa.x, need_lay1, F, need_lay3, need_lay12);
             const int n1 = n + 1;
             int tz = __builtin_ctz(n1);
             if (tz > R - 1) tz = R - 1;
             for (int z = 0; z < nz; z++) {
                 // val = a*J0(a rD) * f(a,p,z) * lapTime(p)                                      (lhs.f90:118)
-                const cplx val = cmul(rscale(aa.y, fast_sample_z<FAMILY, FOLD>(P, F, z)), lt);
+                const cplx val = cmul(rscale(aa.y, fast_sample_z<FAMILY, FOLD, LAY3>(P, F, z)), lt);
                 if (ts) {
                     // tanh-sinh on [0, arg]: abscissa n+1 belongs to level j when 2^(R-j) divides it  (driver.f90:129-157)
                     for (int sh = 0; sh <= tz; sh++) {
@@ -1693,29 +1693,36 @@ static int launch_transform_(const ucf_dev_params& dp, int nwork, int per_point,
 #if UCF_FAST
     if (kind == 1) {
         const size_t ilds = (size_t)(dp.R + 1) * dp.nz * UCF_WAVE * sizeof(lds_c);
-#define UCF_LAUNCH_I(F, W, FO)                                                                                 \
+#define UCF_LAUNCH_I3(F, W, FO, L3)                                                                            \
     do {                                                                                                       \
         if (ilds > 64 * 1024)                                                                                  \
-            (void)hipFuncSetAttribute((const void*)integrate_kernel<F, LAYOUT, W, MULTI, FO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ilds); \
-        hipLaunchKernelGGL((integrate_kernel<F, LAYOUT, W, MULTI, FO>), dim3((unsigned)nwork), block, ilds, s, dp, nwork, per_point, nr, nsv, svmin, \
+            (void)hipFuncSetAttribute((const void*)integrate_kernel<F, LAYOUT, W, MULTI, FO, L3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ilds); \
+        hipLaunchKernelGGL((integrate_kernel<F, LAYOUT, W, MULTI, FO, L3>), dim3((unsigned)nwork), block, ilds, s, dp, nwork, per_point, nr, nsv, svmin, \
                            d_tD, d_rD, d_sv, (const double2*)d_tab, nt, ir0, (double2*)d_state, d_ndone, d_todo, d_params, ppp, pbase); \
+    } while (0)
+        // a depth above the screen top anywhere in the call (always assumed for a parameter batch: layers differ per plan)?
+        bool lay3 = MULTI;
+        for (int i = 0; i < dp.nz; i++) lay3 = lay3 || dp.zLay[i] == 3;
+#define UCF_LAUNCH_FOLD(F, W) UCF_LAUNCH_I3(F, W, true, false)
+#define UCF_LAUNCH_UNF(F, W)                                                                                   \
+    do {                                                                                                       \
+        if (lay3) UCF_LAUNCH_I3(F, W, false, true);                                                            \
+        else UCF_LAUNCH_I3(F, W, false, false);                                                                \
     } while (0)
         const bool w5 = ilds * 20 <= 160 * 1024;
         // fully penetrating pumping well (every plan of a parameter batch must be): the screen terms are compiled out
         const bool fold = dp.fold_dD && dp.fold_lD1 && !MULTI;
         switch (fam) {
-        case 1: if (fold) UCF_LAUNCH_I(1, 4, true); else UCF_LAUNCH_I(1, 4, false); break;
+        case 1: if (fold) UCF_LAUNCH_FOLD(1, 4); else UCF_LAUNCH_UNF(1, 4); break;
         case 2:
-            if (fold) { if (w5) UCF_LAUNCH_I(2, UCF_FOLD_WAVES, true); else UCF_LAUNCH_I(2, 4, true); }
-#ifdef UCF_UNFOLDED_W5
-            else { if (w5) UCF_LAUNCH_I(2, 5, false); else UCF_LAUNCH_I(2, 4, false); }
-#else
-            else UCF_LAUNCH_I(2, UCF_UNFOLD_WAVES, false);   // the screen terms need the registers: 5 waves/SIMD would spill ~50 VGPRs
-#endif
+            if (fold) { if (w5) UCF_LAUNCH_FOLD(2, UCF_FOLD_WAVES); else UCF_LAUNCH_FOLD(2, 4); }
+            else UCF_LAUNCH_UNF(2, UCF_UNFOLD_WAVES);   // the screen terms need the registers: 5 waves/SIMD would spill ~50 VGPRs
             break;
-        case 4: if (fold) UCF_LAUNCH_I(4, 4, true); else UCF_LAUNCH_I(4, 4, false); break;
+        case 4: if (fold) UCF_LAUNCH_FOLD(4, 4); else UCF_LAUNCH_UNF(4, 4); break;
         }
-#undef UCF_LAUNCH_I
+#undef UCF_LAUNCH_FOLD
+#undef UCF_LAUNCH_UNF
+#undef UCF_LAUNCH_I3
     }
 #endif
     if (kind == 2) {

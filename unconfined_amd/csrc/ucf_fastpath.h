@@ -186,7 +186,8 @@ UCF_DEV bool fast_eta(const ucf_dev_params& P, const lane_consts& L, double a, f
 // z-independent part (after fast_eta said yes for every lane of the wave)
 // FOLD: the plan is known to be fully penetrating (fold_dD and fold_lD1), so that none of the screen terms is even
 // compiled in (the launcher picks the instantiation; FOLD = false handles every plan)
-template <int FAMILY, bool FOLD = false>
+// LAY3 = false: the launcher knows that no depth of the call lies above the screen top
+template <int FAMILY, bool FOLD = false, bool LAY3 = true>
 UCF_DEV void fast_common_terms(const ucf_dev_params& P, const lane_consts& L, double a, bool need_lay1_in, fast_common& S,
                                bool need_lay3_in = false, bool need_lay12 = true)
 {
@@ -194,7 +195,7 @@ UCF_DEV void fast_common_terms(const ucf_dev_params& P, const lane_consts& L, do
     const bool hantush = !(FAMILY == 2 && P.model == 4);
     const bool z1 = FOLD || P.fold_dD != 0, z2 = FOLD || P.fold_lD1 != 0;
     const bool need_lay1 = FOLD ? false : need_lay1_in;           // a fully penetrating screen has no layer below it
-    const bool need_lay3 = FOLD ? false : need_lay3_in;           // ... nor above it
+    const bool need_lay3 = (FOLD || !LAY3) ? false : need_lay3_in;   // ... nor above it
     // the water-table closure switches to its exponential form at Re(eta) >= maxexp (:84) and then needs neither
     // cosh(eta) nor sinh(eta): decide per wave what has to be evaluated at all
     S.small_eta = (FAMILY != 2) || (S.eta.re < P.maxexp);                                       // :84
@@ -312,7 +313,7 @@ UCF_DEV bool fast_prepare(const ucf_dev_params& P, const lane_consts& L, double 
 }
 
 // Hantush factor at depth zD (:133-202); chz = cosh(eta*zD) is returned for the closure
-template <int FAMILY, bool FOLD = false>
+template <int FAMILY, bool FOLD = false, bool LAY3 = true>
 UCF_DEV cplx fast_hantush_z(const ucf_dev_params& P, const fast_common& S, double zD, int lay_in, cplx* chz_out,
                             cplx* exz_out)
 {
@@ -344,7 +345,7 @@ UCF_DEV cplx fast_hantush_z(const ucf_dev_params& P, const fast_common& S, doubl
         if (!z2 && FAMILY == 2 && S.any_large) *exz_out = pexpneg(p1z);                         // exp(eta*(zD-1))
         cplx f2c = cmake(0.0, 0.0);
         if (!z2) f2c = cmul(S.ff2, pcosh(p1z));                  // sinh(eta lD1) cosh(eta (1 - zD))
-        if (lay == 2) {
+        if (lay == 2 || !LAY3) {
             if (z1 && z2) return cscale(S.th, P.inv_bD);                                        // g2 = 0: udp = 1
             cplx num = f2c;
             if (!z1) num = cadd(cmul(S.ff1, chz), f2c);
@@ -366,16 +367,16 @@ UCF_DEV cplx fast_hantush_z(const ucf_dev_params& P, const fast_common& S, doubl
     return cscale(cmul(udp, S.th), P.inv_bD);                                                   // :200
 }
 
-template <int FAMILY, bool FOLD = false>
+template <int FAMILY, bool FOLD = false, bool LAY3 = true>
 UCF_DEV cplx fast_sample_z(const ucf_dev_params& P, const fast_common& S, int iz)
 {
     const double zD = P.zD[iz];
     const int lay = P.zLay[iz];
     cplx chz, exz = cmake(0.0, 0.0);
-    if (FAMILY == 1) return fast_hantush_z<1, FOLD>(P, S, zD, lay, &chz, &exz);
+    if (FAMILY == 1) return fast_hantush_z<1, FOLD, LAY3>(P, S, zD, lay, &chz, &exz);
     if (FAMILY == 4) {
-        const cplx sH = fast_hantush_z<4, FOLD>(P, S, zD, lay, &chz, &exz);
-        if (!FOLD && lay == 3) return S.fd_use3 ? cadd(sH, cmul(S.fd_s13, chz)) : sH;
+        const cplx sH = fast_hantush_z<4, FOLD, LAY3>(P, S, zD, lay, &chz, &exz);
+        if (!FOLD && LAY3 && lay == 3) return S.fd_use3 ? cadd(sH, cmul(S.fd_s13, chz)) : sH;
         return S.fd_use ? cadd(sH, cmul(S.fd_s1, chz)) : sH;                                    // :522-525
     }
     cplx u;
@@ -384,10 +385,10 @@ UCF_DEV cplx fast_sample_z(const ucf_dev_params& P, const fast_common& S, int iz
         if (S.any_small) chz = pcosh(prim(S.eta.re * zD, S.eta.im * zD));
         if (S.any_large) { const double c = 1.0 - zD; exz = expneg_direct(S.eta.re * c, S.eta.im * c); }
     } else {
-        u = fast_hantush_z<2, FOLD>(P, S, zD, lay, &chz, &exz);
+        u = fast_hantush_z<2, FOLD, LAY3>(P, S, zD, lay, &chz, &exz);
         if (S.any_large && lay == 1) { const double c = 1.0 - zD; exz = expneg_direct(S.eta.re * c, S.eta.im * c); }
     }
-    const cplx top = (!FOLD && P.model != 4 && lay == 3) ? S.top3 : S.top;
+    const cplx top = (!FOLD && LAY3 && P.model != 4 && lay == 3) ? S.top3 : S.top;
     if (S.small_eta) return csub(u, cmul(cmul(top, chz), S.inv_den));                           // :85-87
     return csub(u, cmul(cmul(top, exz), S.inv_den));                                            // :89-91
 }
