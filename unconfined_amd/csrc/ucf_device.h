@@ -49,6 +49,13 @@ UCF_DEV void stat_add(long long* ctr, bool pred)
     if (bal != 0ull && (threadIdx.x & 63) == 0) atomicAdd((unsigned long long*)ctr, (unsigned long long)__popcll(bal));
 }
 
+// Translation-unit split of the fast flavour (build time): UCF_TU = 0 / 1 / 2 compiles the launchers and the plain
+// kernels of one lane layout only; undefined (-1): everything.
+#ifndef UCF_TU
+#define UCF_TU -1
+#endif
+#define UCF_TU_HAS(L) (UCF_TU < 0 || UCF_TU == (L))
+
 typedef double2 lds_c;   // one complex per lane per slot
 UCF_DEV cplx lds_ld(const lds_c* base, int slot, int lane) { lds_c v = base[slot * UCF_WAVE + lane]; return cmake(v.x, v.y); }
 UCF_DEV void lds_st(lds_c* base, int slot, int lane, cplx z) { base[slot * UCF_WAVE + lane] = make_double2(z.re, z.im); }
@@ -1357,6 +1364,7 @@ finish_kernel(const ucf_dev_params P, int npts, int per_point, int nr, int nsv, 
 // coefficients in LDS (h's in the column the input came from, dh's in a second tile); then 2 x UCF_DH_TILE lanes
 // each finish one vector.  The recurrence used to be uniform work repeated by all 64 lanes for every vector.
 #define UCF_DH_TILE 8
+#if UCF_TU_HAS(1)
 __global__ void __launch_bounds__(UCF_WAVE)
 dehoog_tiles_kernel(const ucf_dev_params P, int nt, int nr, int ir0, int nrc, const double* __restrict__ tDv,
                     const double2* __restrict__ totlap, double* __restrict__ hout, double* __restrict__ dhout,
@@ -1436,9 +1444,12 @@ dehoog_tiles_kernel(const ucf_dev_params P, int nt, int nr, int ir0, int nrc, co
     }
 }
 
+#endif   // UCF_TU_HAS(1)
+
 // second half of LAYOUTs 1 and 2: one wave per point of the chunk, lane = Laplace index (driver.f90:217-230).
 // flat = 0: chunk-local point lp = it*nrc + irl, output at (it*nr + ir0 + irl);  flat = 1: lp is the point itself
 // (tD per point when per_point, else tD[lp / nr]).
+#if UCF_TU_HAS(2)
 __global__ void __launch_bounds__(UCF_WAVE)
 dehoog_points_kernel(const ucf_dev_params P, long long npc, int flat, int per_point, int nr, int ir0, int nrc,
                      const double* __restrict__ tDv, const double2* __restrict__ totlap, double* __restrict__ hout,
@@ -1487,6 +1498,8 @@ dehoog_points_kernel(const ucf_dev_params P, long long npc, int flat, int per_po
         }
     }
 }
+
+#endif   // UCF_TU_HAS(2)
 
 // ------------------------------------------------------------------ stage-hook kernels
 // lap_hank_soln for a list of abscissae: block = abscissa, lane = p index; fp[n_a][nz][np]
@@ -1658,11 +1671,13 @@ static inline int split_kind(const ucf_dev_params& dp)
 #endif
     return 2;
 }
+#if UCF_TU_HAS(1)
 // bytes of state per work item (0: no state needed)
 size_t state_bytes_per_item(const ucf_dev_params& dp)
 {
     return split_kind(dp) ? (size_t)(dp.R + 1 + dp.nacc) * dp.nz * UCF_WAVE * sizeof(lds_c) : 0;
 }
+#endif
 
 // The transform stage for `nwork` work items of lane layout LAYOUT: [integrate kernel -> finish_kernel ->] point_kernel.
 // ev0/ev1 (optional) bracket the dominant kernel: the integrate kernel when there is one, else point_kernel.
@@ -1826,6 +1841,7 @@ static int launch_transform(const ucf_dev_params& dp, int nwork, int per_point, 
                                             d_totlap, d_glscr, d_state, d_ndone, stream, ev0, ev1, nullptr, 1, 0);
 }
 
+#if UCF_TU_HAS(0)
 // LAYOUT 0 (lane = Laplace sample, de Hoog in the same wave)
 int launch_points(const ucf_dev_params& dp, int npts, int per_point, int nr, int nsv, int svmin, const double* d_tD,
                   const double* d_rD, const int* d_sv, const double* d_tab, double* d_h, double* d_dh,
@@ -1836,6 +1852,9 @@ int launch_points(const ucf_dev_params& dp, int npts, int per_point, int nr, int
                                nullptr, d_glscr, d_state, d_ndone, stream, nullptr, nullptr, d_params, ppp, pbase);
 }
 
+#endif
+
+#if UCF_TU_HAS(1)
 // LAYOUT 1 (lane = time): transform kernel(s) over (radius chunk x time tiles x Laplace index), then de Hoog
 int launch_grid_transposed(const ucf_dev_params& dp, int nt, int nr, int ir0, int nrc, int svmin, const double* d_tD,
                            const double* d_rD, const double* d_tab, double* d_totlap, double* d_h, double* d_dh,
@@ -1856,6 +1875,9 @@ int launch_grid_transposed(const ucf_dev_params& dp, int nt, int nr, int ir0, in
     return hipGetLastError() == hipSuccess ? UCF_OK : UCF_ERR_HIP;
 }
 
+#endif
+
+#if UCF_TU_HAS(2)
 // LAYOUT 2 (2M+1 > 64): (point, 64-sample chunk) work items write the transform, dehoog_points_kernel inverts.
 // Same addressing as launch_points; d_h/d_dh/d_totlap point at this chunk of points.
 int launch_points_chunked(const ucf_dev_params& dp, int npts, int per_point, int nr, int nsv, int svmin, const double* d_tD,
@@ -1875,6 +1897,9 @@ int launch_points_chunked(const ucf_dev_params& dp, int npts, int per_point, int
     return hipGetLastError() == hipSuccess ? UCF_OK : UCF_ERR_HIP;
 }
 
+#endif
+
+#if UCF_TU_HAS(1)
 int launch_samples(const ucf_dev_params& dp, int n_a, const double* d_a, double rD, const double* d_p, double* d_fp,
                    void* stream)
 {
@@ -1900,6 +1925,8 @@ int launch_samples(const ucf_dev_params& dp, int n_a, const double* d_a, double 
 #undef UCF_LAUNCH
     return hipGetLastError() == hipSuccess ? UCF_OK : UCF_ERR_HIP;
 }
+
+#endif
 
 #if !UCF_FAST
 int launch_bessel(int n, const double* d_z, double* d_k, int* d_ierr, void* stream)

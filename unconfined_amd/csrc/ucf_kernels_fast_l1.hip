@@ -1,0 +1,6 @@
+// "fast" flavour, translation unit of lane layout 1 (see UCF_TU in ucf_device.h; ucf_kernels_fast.hip = all of them,
+// used by the inspection tools)
+#define UCF_FAST 1
+#define UCF_NS ucf_fast
+#define UCF_TU 1
+#include "ucf_device.h"

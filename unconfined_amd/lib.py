@@ -41,7 +41,7 @@ class UcfError(RuntimeError):
 
 def build(verbose: bool = False) -> str:
     """compile the HIP library in-tree (hipcc, gfx950); returns the .so path"""
-    res = subprocess.run(["make", "-C", os.path.join(HERE, "csrc"), "-j4"], capture_output=True, text=True)
+    res = subprocess.run(["make", "-C", os.path.join(HERE, "csrc"), "-j6"], capture_output=True, text=True)
     if verbose or res.returncode:
         print(res.stdout[-4000:])
         print(res.stderr[-4000:])
