@@ -31,7 +31,7 @@ UCF_DEV double exp_pos(double x)
 #else
 #define K(c) (c)
 #endif
-    const double k = __builtin_rint(mulk(x, K(1.4426950408889634074)));
+    const double k = __builtin_rint(x * 1.4426950408889634074);      // (plain product: lets |x| / -x fold into the operand)
     double r = __builtin_fma(-k, 6.93147180369123816490e-01, x);
     r = __builtin_fma(-k, 1.90821492927058770002e-10, r);
     // 1 + r + r^2 s(r), s of degree 9 interpolating (e^r - 1 - r)/r^2 at the Chebyshev nodes of |r| <= 0.34665
