@@ -405,9 +405,22 @@ for name in ("c2_neuman74_fullpen", "neuman74_partpen"):
     tD = 10.0 ** np.linspace(-2, 4, 150); sv = plan.split_vector(tD)
     rD = np.array([0.02, 0.1, 0.7, 3.0, 9.0])          # 0.02: overflow regime -> unfinished items -> point_kernel
     h, dh = plan.drawdown_grid(tD, sv, rD, zD, zl)
-    TT, RR = np.meshgrid(tD[::7], rD, indexing="ij")
-    hb, dhb = plan.drawdown(TT.ravel(), RR.ravel(), np.repeat(sv[::7], len(rD)), zD, zl)
+    TT, RR = np.meshgrid(tD[::2], rD, indexing="ij")          # 375 points: enough for the lane = point layout
+    hb, dhb = plan.drawdown(TT.ravel(), RR.ravel(), np.repeat(sv[::2], len(rD)), zD, zl)
     out[name + "_h"], out[name + "_dh"], out[name + "_hb"], out[name + "_dhb"] = h, dh, hb, dhb
+# a parameter batch: 5 sets x 300 observation points, against the same sets one by one
+from unconfined_amd.abi import params_from_deck
+dk, ts, P = load_deck("neuman74_partpen")
+plans = [engine.Plan(params_from_deck(dk.replace(Kr=dk.Kr * (0.6 + 0.2 * i), kappa=dk.kappa * (0.5 + 0.3 * i))), mode="fast") for i in range(5)]
+rng = np.random.default_rng(3)
+t = 10.0 ** rng.uniform(-1, 4, 300); r = rng.choice([30.0, 85.1, 400.0], 300); z = np.array([145.7, 60.0])
+hm, dhm = engine.drawdown_multi(plans, t, r, z)
+out["multi_h"], out["multi_dh"] = hm, dhm
+for k, pl in enumerate(plans):
+    D = pl.derived
+    tDk, rDk, zDk = t / D.Tc, r / D.Lc, z / D.Lc
+    h1, dh1 = pl.drawdown(tDk, rDk, pl.split_vector(tDk), zDk, pl.zlay(zDk))
+    out[f"single_h{k}"], out[f"single_dh{k}"] = h1 * D.Hc, dh1 * D.Hc
 np.savez(sys.argv[2], **out)
 """
 
@@ -419,18 +432,32 @@ def test_pipeline_knobs_do_not_change_results(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
     for tag, env in (("default", {}), ("chunks", {"UCF_STATE_BYTES": str(3 << 20)}), ("part16", {"UCF_FINISH_PART": "16"}),
-                     ("part32", {"UCF_FINISH_PART": "32"})):
+                     ("part32", {"UCF_FINISH_PART": "32"}), ("tables", {"UCF_TABLE_BYTES": str(3 << 20)}),
+                     ("lane_sample", {"UCF_BATCH_LAYOUT": "0"})):
         out = str(tmp_path / f"{tag}.npz")
         e = dict(os.environ); e.update(env)
         subprocess.run([sys.executable, "-c", _PIPE_SCRIPT, root, out], check=True, env=e, timeout=600)
         res[tag] = np.load(out)
     ref = res["default"]
-    for tag in ("chunks", "part16", "part32"):
+    for tag in ("chunks", "part16", "part32", "tables"):
         for k in ref.files:
             assert np.array_equal(ref[k], res[tag][k], equal_nan=True), (tag, k)
+    # the parameter batch equals its plans one by one, whatever the chunking
+    for tag in ("default", "chunks", "tables", "lane_sample"):
+        for k in range(5):
+            assert np.array_equal(res[tag]["multi_h"][k], res[tag][f"single_h{k}"], equal_nan=True), (tag, k)
+            assert np.array_equal(res[tag]["multi_dh"][k], res[tag][f"single_dh{k}"], equal_nan=True), (tag, k)
+    # lane = point and lane = Laplace sample layouts of a point list: same per-lane arithmetic
+    for k in ref.files:
+        a, b = ref[k], res["lane_sample"][k]
+        assert np.array_equal(np.isnan(a), np.isnan(b)), k
+        if k.endswith("_hb") or k.startswith("multi_h") or k.startswith("single_h"):
+            sel = (slice(None), slice(1, None)) if k.endswith("_hb") and False else slice(None)
+            fin = np.isfinite(a)
+            assert rel_err(a[fin], b[fin], 1e-6).max() < 1e-6, k
     # grid (lane = time) and batch (lane = Laplace sample) agree to rounding of the fast flavour's contractions
     for name in ("c2_neuman74_fullpen", "neuman74_partpen"):
-        hg = ref[name + "_h"][::7]; hb = ref[name + "_hb"].reshape(hg.shape)
+        hg = ref[name + "_h"][::2]; hb = ref[name + "_hb"].reshape(hg.shape)
         assert np.array_equal(np.isnan(hg), np.isnan(hb))
         assert rel_err(hg[:, 1:], hb[:, 1:], 1e-6).max() < 1e-6, name      # (column 0 is the overflow regime)
 

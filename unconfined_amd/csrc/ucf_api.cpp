@@ -234,6 +234,8 @@ int fill_call_params(const ucf_plan* plan, int nz, const double* zD, const int* 
         dp.zD[i] = zD[i];
         dp.zLay[i] = zLay[i];
     }
+    dp.any_lay3 = 0;
+    for (int i = 0; i < nz; i++) dp.any_lay3 |= (zLay[i] == 3);
     // the fast evaluators take sin/cos of Im(eta)*c for c in {1, dD, 1-lD, dD1-1, zD, 1-zD, dD1-zD}:
     // the largest |c| bounds the argument (two-stage Cody-Waite reduction is good below 1e6)
     double cmax = 1.0;
@@ -624,6 +626,12 @@ int ensure_state(ucf_plan* pl, const ucf_dev_params& dp, size_t items)
     }
     return UCF_OK;
 }
+// abscissa-table bytes per chunk of an arbitrary point list (UCF_TABLE_BYTES, default 256 MiB)
+size_t table_budget()
+{
+    static const size_t b = [] { const char* e = std::getenv("UCF_TABLE_BYTES"); long long v = e ? std::atoll(e) : 0; return v > 0 ? (size_t)v : ((size_t)256 << 20); }();
+    return b;
+}
 // work items per launch such that their state stays within UCF_STATE_BYTES (default 8 GiB of the 288 GB)
 size_t state_budget()
 {
@@ -631,26 +639,53 @@ size_t state_budget()
     return b;
 }
 
+// lane layout of arbitrary point lists: 3 = lane is a point (all 64 lanes live whatever M is), 0 = lane is a Laplace
+// sample (2M+1 of 64 lanes live).  UCF_BATCH_LAYOUT=0 forces the latter (diagnostic).
+int batch_layout()
+{
+    static const int v = [] { const char* e = std::getenv("UCF_BATCH_LAYOUT"); return e ? std::atoi(e) : 3; }();
+    return v;
+}
+
 int launch_points_any(ucf_plan* pl, const ucf_dev_params& dp, int npts, int per_point, int nr, int nsv, int svmin,
                       const double* d_tD, const double* d_rD, const int* d_sv, double* d_h, double* d_dh,
-                      ucf_stats* d_stats, void* stream, const ucf_dev_params* d_params = nullptr, int ppp = 1)
+                      ucf_stats* d_stats, void* stream, const ucf_dev_params* d_params = nullptr, int ppp = 1, size_t p0 = 0,
+                      int npts_call = -1)
 {
+    // (d_params: parameter batch, plan of point q of this call = (p0 + q) / ppp; p0 must be a multiple of ppp)
     int rc = ensure_glscr(pl, dp.nz);
     if (rc) return rc;
     const bool chunked = pl->D.np > UCF_WAVE;     // more Laplace samples than lanes: (point, 64-sample chunk) work items
-    const int items_per_pt = chunked ? (pl->D.np + UCF_WAVE - 1) / UCF_WAVE : 1;
-    // points per launch: bounded by the integration-state budget; a grid (per_point = 0) is cut at whole time rows
-    size_t step = (size_t)npts;
     const size_t per_item = state_item_bytes(pl, dp);
-    if (per_item) {
+    // lane = point when that fills the waves better and the abscissa loop has its own kernel
+    // (decided on the size of the whole call, npts_call, so that the chunking of a long list cannot change a bit)
+    const bool lanes = batch_layout() == 3 && per_point && !chunked && per_item != 0 && !pl->force_layout0 &&
+                       (npts_call >= 0 ? npts_call : npts) >= 4 * UCF_WAVE && (!d_params || ppp >= UCF_WAVE / 2);
+    const int items_per_pt = chunked ? (pl->D.np + UCF_WAVE - 1) / UCF_WAVE : 1;
+    // points per launch: bounded by the integration-state budget; a grid (per_point = 0) is cut at whole time rows,
+    // a parameter batch in the lane = point layout at whole plans
+    size_t step = (size_t)npts;
+    size_t items = 0;
+    if (lanes) {
+        const size_t unit = d_params ? (size_t)ppp : UCF_WAVE;                                   // points that go together
+        const size_t unit_items = (size_t)((unit + UCF_WAVE - 1) / UCF_WAVE) * pl->D.np;          // their work items
+        size_t nunits = state_budget() / (per_item * unit_items);
+        if (nunits < 1) nunits = 1;
+        step = nunits * unit;
+        if (step > (size_t)npts) step = npts;
+        items = ((step + unit - 1) / unit) * unit_items;
+    } else if (per_item) {
         step = state_budget() / (per_item * items_per_pt);
         if (!per_point) step = (step / nr) * nr;
         if (step < (size_t)(per_point ? 1 : nr)) step = per_point ? 1 : nr;
         if (step > (size_t)npts) step = npts;
-        rc = ensure_state(pl, dp, step * items_per_pt);
+        items = step * items_per_pt;
+    }
+    if (per_item) {
+        rc = ensure_state(pl, dp, items);
         if (rc) return rc;
     }
-    if (chunked) {
+    if (chunked || lanes) {
         const size_t need = step * dp.nz * pl->D.np * 2 * sizeof(double);
         if (pl->totlap_bytes < need) {
             if (pl->d_totlap) { (void)hipDeviceSynchronize(); (void)hipFree(pl->d_totlap); pl->d_totlap = nullptr; pl->totlap_bytes = 0; }
@@ -669,13 +704,18 @@ int launch_points_any(ucf_plan* pl, const ucf_dev_params& dp, int npts, int per_
         const double* tab = per_point ? pl->d_work + base * nabs * 2 : pl->d_work;
         double* h = d_h + base * dp.nz_out;
         double* dh = d_dh + base * dp.nz_out;
-        if (chunked) {
+        if (lanes) {
+            const int pp = d_params ? ppp : n;
             rc = (pl->mode == 1)
-                     ? ucf_fast::launch_points_chunked(dp, n, per_point, nr, nsv, svmin, tD, rD, sv, tab, pl->d_totlap, h, dh, d_stats, stream, pl->d_glscr, pl->d_state, pl->d_ndone, d_params, ppp, (int)base)
+                     ? ucf_fast::launch_points_lanes(dp, n, pp, tD, rD, sv, tab, pl->d_totlap, h, dh, d_stats, stream, pl->d_state, pl->d_ndone, d_params, (int)(p0 + base))
+                     : ucf_faithful::launch_points_lanes(dp, n, pp, tD, rD, sv, tab, pl->d_totlap, h, dh, d_stats, stream, pl->d_state, pl->d_ndone, nullptr, 0);
+        } else if (chunked) {
+            rc = (pl->mode == 1)
+                     ? ucf_fast::launch_points_chunked(dp, n, per_point, nr, nsv, svmin, tD, rD, sv, tab, pl->d_totlap, h, dh, d_stats, stream, pl->d_glscr, pl->d_state, pl->d_ndone, d_params, ppp, (int)(p0 + base))
                      : ucf_faithful::launch_points_chunked(dp, n, per_point, nr, nsv, svmin, tD, rD, sv, tab, pl->d_totlap, h, dh, d_stats, stream, pl->d_glscr, pl->d_state, pl->d_ndone);
         } else {
             rc = (pl->mode == 1)
-                     ? ucf_fast::launch_points(dp, n, per_point, nr, nsv, svmin, tD, rD, sv, tab, h, dh, d_stats, stream, pl->d_glscr, pl->d_state, pl->d_ndone, d_params, ppp, (int)base)
+                     ? ucf_fast::launch_points(dp, n, per_point, nr, nsv, svmin, tD, rD, sv, tab, h, dh, d_stats, stream, pl->d_glscr, pl->d_state, pl->d_ndone, d_params, ppp, (int)(p0 + base))
                      : ucf_faithful::launch_points(dp, n, per_point, nr, nsv, svmin, tD, rD, sv, tab, h, dh, d_stats, stream, pl->d_glscr, pl->d_state, pl->d_ndone);
         }
         if (rc == UCF_ERR_UNSUPPORTED) return fail(rc, "this model / size combination has no kernel (model %d, LDS limit)", dp.model);
@@ -805,7 +845,7 @@ int batch_device_chunk(ucf_plan* pl, int npts, const double* d_tD, const double*
     if (rc) return rc;
     // arbitrary points: one table row per point, in chunks that keep the workspace <= 256 MiB
     const size_t row_bytes = (size_t)pl->D.nabs * 2 * sizeof(double);
-    int chunk = (int)((256u << 20) / row_bytes);
+    int chunk = (int)(table_budget() / row_bytes);
     if (chunk < 1) chunk = 1;
     if (chunk > npts) chunk = npts;
     rc = ensure_work(pl, (size_t)chunk * row_bytes);
@@ -815,7 +855,7 @@ int batch_device_chunk(ucf_plan* pl, int npts, const double* d_tD, const double*
         rc = ucf_faithful::launch_abscissae(dp, n, 1, 1, 0, d_rD + base, d_sv + base, pl->d_work, stream);
         if (rc) return fail(rc, "abscissa kernel launch failed");
         rc = launch_points_any(pl, dp, n, 1, 1, 1, 0, d_tD + base, d_rD + base, d_sv + base, d_h + (size_t)base * nz_out,
-                               d_dh + (size_t)base * nz_out, d_stats, stream);
+                               d_dh + (size_t)base * nz_out, d_stats, stream, nullptr, 1, 0, npts);
         if (rc) return rc;
     }
     return UCF_OK;
@@ -947,8 +987,9 @@ int ucf_drawdown_multi(ucf_plan* const* plans, int nplans, int npts, const doubl
         if (b_p.alloc(sizeof(ucf_dev_params) * nplans)) return fail(UCF_ERR_NOMEM, "device allocation failed for %d parameter blocks", nplans);
         // one abscissa row per (plan, point), in chunks that keep the table <= 256 MiB
         const size_t row_bytes = (size_t)pl->D.nabs * 2 * sizeof(double);
-        size_t chunk = ((size_t)256 << 20) / row_bytes;
-        if (chunk < 1) chunk = 1;
+        size_t chunk_plans = (table_budget() / row_bytes) / np_;      // whole plans per table chunk
+        if (chunk_plans < 1) chunk_plans = 1;
+        size_t chunk = chunk_plans * np_;
         if (chunk > tot) chunk = tot;
         int rc = ensure_work(pl, chunk * row_bytes);
         if (rc) return rc;
@@ -960,6 +1001,7 @@ int ucf_drawdown_multi(ucf_plan* const* plans, int nplans, int npts, const doubl
                 rc = fill_call_params(plans[k], nzc, &zD[(size_t)k * nz + z0], &zl[(size_t)k * nz + z0], dps[k], nz, z0);
                 if (rc) return rc;
             }
+            for (int k = 1; k < nplans; k++) dps[0].any_lay3 |= dps[k].any_lay3;      // plan 0's block drives the launch
             HIP_TRY(hipDeviceSynchronize());                              // the previous chunk still reads the parameter blocks
             HIP_TRY(hipMemcpy(b_p.p, dps.data(), sizeof(ucf_dev_params) * nplans, hipMemcpyHostToDevice));
             for (size_t base = 0; base < tot && rc == UCF_OK; base += chunk) {
@@ -969,7 +1011,7 @@ int ucf_drawdown_multi(ucf_plan* const* plans, int nplans, int npts, const doubl
                 // points [base, base + n) of the flattened (plan, point) index; plan of point q = q / npts
                 rc = launch_points_any(pl, dps[0], n, 1, 1, 1, 0, (const double*)b_t.p + base, (const double*)b_r.p + base,
                                        (const int*)b_s.p + base, (double*)b_h.p + base * nz, (double*)b_d.p + base * nz, nullptr, nullptr,
-                                       (const ucf_dev_params*)b_p.p + 0, npts);
+                                       (const ucf_dev_params*)b_p.p, npts, base, (int)tot);
                 if (rc) return rc;
                 if (base + chunk < tot) HIP_TRY(hipDeviceSynchronize());      // the next chunk rewrites the table
             }

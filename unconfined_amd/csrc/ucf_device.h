@@ -911,13 +911,14 @@ abscissa_kernel(const ucf_dev_params P, int nrows, int per_point, int nsv, int s
 //             so both give the same bits.
 // decoding of a work-item index into (time, radius, Laplace index), shared by the kernels below
 struct work_item {
-    int it, ir, mlap, pidx;
+    int it, ir, mlap, pidx, plan;
     bool live;
 };
 template <int LAYOUT>
 UCF_DEV work_item decode_item(const ucf_dev_params& P, int pt, int lane, int per_point, int nr, int nt, int ir0)
 {
     work_item W;
+    W.plan = 0;
     if (LAYOUT == 0) {
         W.it = per_point ? pt : pt / nr;
         W.ir = per_point ? pt : pt % nr;
@@ -933,6 +934,19 @@ UCF_DEV work_item decode_item(const ucf_dev_params& P, int pt, int lane, int per
         W.mlap = (pt % nchunk) * UCF_WAVE + lane;
         W.live = W.mlap < P.np;
         W.pidx = q;
+    } else if (LAYOUT == 3) {
+        // lane = point of an arbitrary point list: work item = (tile of 64 points, Laplace index), all lanes live
+        // whatever M is; times, radii, split indices and abscissa rows are per lane.  nr = points per plan (a
+        // parameter batch cuts its tiles per plan so that a wave never straddles two parameter blocks), nt = points
+        // of the launch
+        const int tpp = (nr + UCF_WAVE - 1) / UCF_WAVE;
+        const int tile = pt / P.np;
+        W.mlap = pt % P.np;
+        W.plan = tile / tpp;
+        const int qin = (tile % tpp) * UCF_WAVE + lane;
+        W.live = qin < nr;
+        W.pidx = W.plan * nr + (W.live ? qin : nr - 1);
+        W.it = W.ir = W.pidx;
     } else {
         // work item = (radius of this chunk, tile of 64 times, Laplace index); m fastest so that
         // neighbouring waves share the abscissa row and the times
@@ -1016,6 +1030,9 @@ UCF_DEV void finish_item(const ucf_dev_params& P, lds_c* accTS, lds_c* scr, cons
         if (LAYOUT == 1) {
             // [radius of the chunk][z][m][time]: the 64 lanes (consecutive times) store 1 KB contiguously
             if (W.live) totlap[(((size_t)(W.ir - ir0) * nz + z) * P.np + W.mlap) * nt + W.it] = make_double2(tl.re, tl.im);
+        } else if (LAYOUT == 3) {
+            // [z][m][point]: the same, the points of the launch in the place of the times of one radius
+            if (W.live) totlap[((size_t)z * P.np + W.mlap) * nt + W.it] = make_double2(tl.re, tl.im);
         } else if (LAYOUT == 2) {
             if (W.live) totlap[((size_t)W.pidx * nz + z) * P.np + W.mlap] = make_double2(tl.re, tl.im);
         } else {
@@ -1076,7 +1093,7 @@ point_kernel(const ucf_dev_params P0, int npts, int per_point, int nr, int nsv, 
         const int pt = resume ? todo[1 + wi] : wi;
         const work_item W = decode_item<LAYOUT>(P0, pt, lane, per_point, nr, nt, ir0);
         const int it = W.it, ir = W.ir, mlap = W.mlap, pidx = W.pidx;
-        const ucf_dev_params& P = item_params<MULTI>(P0, Pv, pidx + pbase, ppp);
+        const ucf_dev_params& P = item_params<MULTI>(P0, Pv, (LAYOUT == 3 ? W.plan * ppp : pidx) + pbase, ppp);
         bool need_lay1 = false;
         for (int z = 0; z < nz; z++) need_lay1 |= (P.zLay[z] == 1);
         const double tD = tDv[it], rD = rDv[ir];
@@ -1177,7 +1194,7 @@ integrate_kernel(const ucf_dev_params P0, int npts, int per_point, int nr, int n
     lds_c* accCur = lds + (size_t)R * nz * UCF_WAVE;        // [nz]     area of the J0 interval being integrated
     for (int pt = blockIdx.x; pt < npts; pt += gridDim.x) {
         const work_item W = decode_item<LAYOUT>(P0, pt, lane, per_point, nr, nt, ir0);
-        const ucf_dev_params& P = item_params<MULTI>(P0, Pv, W.pidx + pbase, ppp);
+        const ucf_dev_params& P = item_params<MULTI>(P0, Pv, (LAYOUT == 3 ? W.plan * ppp : W.pidx) + pbase, ppp);
         bool need_lay1 = false, need_lay3 = false, need_lay12 = false;
         for (int z = 0; z < nz; z++) { need_lay1 |= (P.zLay[z] == 1); need_lay3 |= (P.zLay[z] == 3); need_lay12 |= (P.zLay[z] != 3); }
         const double tD = tDv[W.it], rD = rDv[W.ir];
@@ -1364,7 +1381,8 @@ finish_kernel(const ucf_dev_params P, int npts, int per_point, int nr, int nsv, 
 // coefficients in LDS (h's in the column the input came from, dh's in a second tile); then 2 x UCF_DH_TILE lanes
 // each finish one vector.  The recurrence used to be uniform work repeated by all 64 lanes for every vector.
 #define UCF_DH_TILE 8
-#if UCF_TU_HAS(1)
+#if UCF_TU_HAS(1) || UCF_TU_HAS(3)
+template <int TU>          // (a template only so that two translation units may hold it)
 __global__ void __launch_bounds__(UCF_WAVE)
 dehoog_tiles_kernel(const ucf_dev_params P, int nt, int nr, int ir0, int nrc, const double* __restrict__ tDv,
                     const double2* __restrict__ totlap, double* __restrict__ hout, double* __restrict__ dhout,
@@ -1444,7 +1462,7 @@ dehoog_tiles_kernel(const ucf_dev_params P, int nt, int nr, int ir0, int nrc, co
     }
 }
 
-#endif   // UCF_TU_HAS(1)
+#endif   // UCF_TU_HAS(1) || UCF_TU_HAS(3)
 
 // second half of LAYOUTs 1 and 2: one wave per point of the chunk, lane = Laplace index (driver.f90:217-230).
 // flat = 0: chunk-local point lp = it*nrc + irl, output at (it*nr + ir0 + irl);  flat = 1: lp is the point itself
@@ -1715,9 +1733,8 @@ static int launch_transform_(const ucf_dev_params& dp, int nwork, int per_point,
         hipLaunchKernelGGL((integrate_kernel<F, LAYOUT, W, MULTI, FO, L3>), dim3((unsigned)nwork), block, ilds, s, dp, nwork, per_point, nr, nsv, svmin, \
                            d_tD, d_rD, d_sv, (const double2*)d_tab, nt, ir0, (double2*)d_state, d_ndone, d_todo, d_params, ppp, pbase); \
     } while (0)
-        // a depth above the screen top anywhere in the call (always assumed for a parameter batch: layers differ per plan)?
-        bool lay3 = MULTI;
-        for (int i = 0; i < dp.nz; i++) lay3 = lay3 || dp.zLay[i] == 3;
+        // a depth above the screen top anywhere in the call (in any plan of a parameter batch)?
+        const bool lay3 = dp.any_lay3 != 0;
 #define UCF_LAUNCH_FOLD(F, W) UCF_LAUNCH_I3(F, W, true, false)
 #define UCF_LAUNCH_UNF(F, W)                                                                                   \
     do {                                                                                                       \
@@ -1830,7 +1847,7 @@ static int launch_transform(const ucf_dev_params& dp, int nwork, int per_point, 
 {
 #if UCF_FAST
     if (d_params) {
-        if (LAYOUT == 1 || !per_point) return UCF_ERR_BAD_ARGUMENT;
+        if (LAYOUT == 1 || !per_point) return UCF_ERR_BAD_ARGUMENT;      // (layouts 0, 2, 3)
         return launch_transform_<(LAYOUT == 1 ? 0 : LAYOUT), true>(dp, nwork, per_point, nr, nsv, svmin, d_tD, d_rD, d_sv, d_tab, d_h, d_dh, d_stats, nt,
                                                                   ir0, nrc, d_totlap, d_glscr, d_state, d_ndone, stream, ev0, ev1, d_params, ppp, pbase);
     }
@@ -1870,11 +1887,33 @@ int launch_grid_transposed(const ucf_dev_params& dp, int nt, int nr, int ir0, in
     if (rc) return rc;
     const long long ntl = (long long)nrc * ((nt + UCF_DH_TILE - 1) / UCF_DH_TILE);
     const size_t dlds = 2 * (size_t)dp.np * (UCF_DH_TILE + 1) * sizeof(lds_c) + 2 * UCF_DH_TILE * sizeof(int);
-    hipLaunchKernelGGL(dehoog_tiles_kernel, dim3((unsigned)(ntl > 0x7fffffffLL ? 0x7fffffff : ntl)), dim3(UCF_WAVE), dlds, s, dp, nt, nr, ir0,
+    hipLaunchKernelGGL(dehoog_tiles_kernel<1>, dim3((unsigned)(ntl > 0x7fffffffLL ? 0x7fffffff : ntl)), dim3(UCF_WAVE), dlds, s, dp, nt, nr, ir0,
                        nrc, d_tD, (const double2*)d_totlap, d_h, d_dh, d_stats);
     return hipGetLastError() == hipSuccess ? UCF_OK : UCF_ERR_HIP;
 }
 
+#endif
+
+#if UCF_TU_HAS(3)
+// LAYOUT 3 (lane = point of an arbitrary list, 2M+1 <= 64): npts points, ppp of them per plan (npts for one plan);
+// transform over (64-point tiles x Laplace index), then the tiled de Hoog with the points in the place of the times
+int launch_points_lanes(const ucf_dev_params& dp, int npts, int ppp, const double* d_tD, const double* d_rD, const int* d_sv,
+                        const double* d_tab, double* d_totlap, double* d_h, double* d_dh, ucf_stats* d_stats, void* stream,
+                        double* d_state, int* d_ndone, const ucf_dev_params* d_params, int pbase)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (ppp < 1 || npts % ppp != 0 || dp.np > UCF_WAVE) return UCF_ERR_BAD_ARGUMENT;
+    const long long nwork = (long long)(npts / ppp) * ((ppp + UCF_WAVE - 1) / UCF_WAVE) * dp.np;
+    if (nwork > 0x7fffffffLL) return UCF_ERR_BAD_ARGUMENT;
+    int rc = launch_transform<3>(dp, (int)nwork, 1, ppp, 1, 0, d_tD, d_rD, d_sv, d_tab, d_h, d_dh, d_stats, npts, 0, 0, d_totlap, nullptr,
+                                 d_state, d_ndone, stream, nullptr, nullptr, d_params, ppp, pbase);
+    if (rc) return rc;
+    const long long ntl = (npts + UCF_DH_TILE - 1) / UCF_DH_TILE;
+    const size_t dlds = 2 * (size_t)dp.np * (UCF_DH_TILE + 1) * sizeof(lds_c) + 2 * UCF_DH_TILE * sizeof(int);
+    hipLaunchKernelGGL(dehoog_tiles_kernel<3>, dim3((unsigned)ntl), dim3(UCF_WAVE), dlds, s, dp, npts, 1, 0, 1, d_tD,
+                       (const double2*)d_totlap, d_h, d_dh, d_stats);
+    return hipGetLastError() == hipSuccess ? UCF_OK : UCF_ERR_HIP;
+}
 #endif
 
 #if UCF_TU_HAS(2)

@@ -14,7 +14,7 @@ extern int ucf_finish_part;   /* diagnostic: lanes per scratch part in finish_ke
 struct ucf_dev_params {
     int model, MNtype, order, timeType, MoenchM;
     int M, np, k, N, R, nacc, ngl, nz;
-    int nj0z, _pad;
+    int nj0z, any_lay3;    // any_lay3: some depth of the launch (of any plan of a parameter batch) lies above the screen top
     int nz_out, z_off;     // depths of the whole call / offset of this launch's chunk: out index = pt*nz_out + z_off + z
     double timePar[2];
     double kappa, alphaD, beta;
@@ -96,6 +96,9 @@ int launch_points_chunked(const ucf_dev_params& dp, int npts, int per_point, int
 int launch_grid_transposed(const ucf_dev_params& dp, int nt, int nr, int ir0, int nrc, int svmin, const double* d_tD,
                            const double* d_rD, const double* d_tab, double* d_totlap, double* d_h, double* d_dh,
                            ucf_stats* d_stats, void* stream, void* ev0, void* ev1, double* d_glscr, double* d_state, int* d_ndone);
+int launch_points_lanes(const ucf_dev_params& dp, int npts, int ppp, const double* d_tD, const double* d_rD, const int* d_sv,
+                        const double* d_tab, double* d_totlap, double* d_h, double* d_dh, ucf_stats* d_stats, void* stream,
+                        double* d_state, int* d_ndone, const ucf_dev_params* d_params = nullptr, int pbase = 0);
 int launch_samples(const ucf_dev_params& dp, int n_a, const double* d_a, double rD, const double* d_p, double* d_fp,
                    void* stream);
 int launch_bessel(int n, const double* d_z, double* d_k, int* d_ierr, void* stream);
@@ -117,6 +120,9 @@ int launch_points(const ucf_dev_params& dp, int npts, int per_point, int nr, int
                   const double* d_rD, const int* d_sv, const double* d_tab, double* d_h, double* d_dh,
                   ucf_stats* d_stats, void* stream, double* d_glscr, double* d_state, int* d_ndone,
                   const ucf_dev_params* d_params = nullptr, int ppp = 1, int pbase = 0);
+int launch_points_lanes(const ucf_dev_params& dp, int npts, int ppp, const double* d_tD, const double* d_rD, const int* d_sv,
+                        const double* d_tab, double* d_totlap, double* d_h, double* d_dh, ucf_stats* d_stats, void* stream,
+                        double* d_state, int* d_ndone, const ucf_dev_params* d_params = nullptr, int pbase = 0);
 int launch_samples(const ucf_dev_params& dp, int n_a, const double* d_a, double rD, const double* d_p, double* d_fp,
                    void* stream);
 // bytes of integrate_kernel -> point_kernel state per work item (0 where the flavour / model has no integrate_kernel)
