@@ -462,6 +462,40 @@ def test_pipeline_knobs_do_not_change_results(tmp_path):
         assert rel_err(hg[:, 1:], hb[:, 1:], 1e-6).max() < 1e-6, name      # (column 0 is the overflow regime)
 
 
+_LAYOUT_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+from golden_util import load_deck
+from unconfined_amd import engine
+out = {}
+for name in ("c2_neuman74_fullpen", "neuman74_partpen", "hantush_lay3", "hstorage_partpen_lay1", "c1_theis", "mishra_fd30"):
+    dk, ts, P = load_deck(name)
+    plan = engine.Plan(P, mode="faithful")
+    rng = np.random.default_rng(5)
+    tD = 10.0 ** rng.uniform(-2, 4, 400); rD = 10.0 ** rng.uniform(-1, 1, 400); sv = plan.split_vector(tD)
+    zD = np.array([0.3, 0.95]); zl = plan.zlay(zD)
+    h, dh = plan.drawdown(tD, rD, sv, zD, zl)
+    out[name + "_h"], out[name + "_dh"] = h, dh
+np.savez(sys.argv[2], **out)
+"""
+
+
+def test_point_list_layouts_same_bits_faithful(tmp_path):
+    """a list of 400 arbitrary points in the lane = point and in the lane = Laplace-sample layout: the faithful
+    flavour gives the same bits (six models, all layers)"""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for tag, env in (("point", {}), ("sample", {"UCF_BATCH_LAYOUT": "0"})):
+        out = str(tmp_path / f"{tag}.npz")
+        e = dict(os.environ); e.update(env)
+        subprocess.run([sys.executable, "-c", _LAYOUT_SCRIPT, root, out], check=True, env=e, timeout=600)
+        res[tag] = np.load(out)
+    for k in res["point"].files:
+        assert np.isfinite(res["point"][k]).any()
+        assert np.array_equal(res["point"][k], res["sample"][k], equal_nan=True), k
+
+
 def test_parameter_batched_sweep(engine):
     """f4: the same observation points under 12 parameter sets in one call == 12 single-plan calls"""
     from unconfined_amd.abi import params_from_deck
