@@ -408,6 +408,13 @@ for name in ("c2_neuman74_fullpen", "neuman74_partpen"):
     TT, RR = np.meshgrid(tD[::2], rD, indexing="ij")          # 375 points: enough for the lane = point layout
     hb, dhb = plan.drawdown(TT.ravel(), RR.ravel(), np.repeat(sv[::2], len(rD)), zD, zl)
     out[name + "_h"], out[name + "_dh"], out[name + "_hb"], out[name + "_dhb"] = h, dh, hb, dhb
+    # a short time vector against many radii: the library expands such a grid into its point list (lane = point)
+    ts_, rs_ = tD[::20], 10.0 ** np.linspace(-1, 1, 80)
+    hs, dhs = plan.drawdown_grid(ts_, sv[::20], rs_, zD, zl)
+    T2, R2 = np.meshgrid(ts_, rs_, indexing="ij")
+    hp, dhp = plan.drawdown(T2.ravel(), R2.ravel(), np.repeat(sv[::20], len(rs_)), zD, zl)
+    out[name + "_hs"], out[name + "_hp"] = hs, hp.reshape(hs.shape)
+    out[name + "_dhs"], out[name + "_dhp"] = dhs, dhp.reshape(dhs.shape)
 # a parameter batch: 5 sets x 300 observation points, against the same sets one by one
 from unconfined_amd.abi import params_from_deck
 dk, ts, P = load_deck("neuman74_partpen")
@@ -442,6 +449,11 @@ def test_pipeline_knobs_do_not_change_results(tmp_path):
     for tag in ("chunks", "part16", "part32", "tables"):
         for k in ref.files:
             assert np.array_equal(ref[k], res[tag][k], equal_nan=True), (tag, k)
+    # a short-time-vector grid equals the point list it stands for
+    for tag in ("default", "chunks", "tables"):
+        for name in ("c2_neuman74_fullpen", "neuman74_partpen"):
+            assert np.array_equal(res[tag][name + "_hs"], res[tag][name + "_hp"], equal_nan=True), (tag, name)
+            assert np.array_equal(res[tag][name + "_dhs"], res[tag][name + "_dhp"], equal_nan=True), (tag, name)
     # the parameter batch equals its plans one by one, whatever the chunking
     for tag in ("default", "chunks", "tables", "lane_sample"):
         for k in range(5):

@@ -440,6 +440,7 @@ void ucf_plan_destroy(ucf_plan* pl)
     if (pl->d_work) (void)hipFree(pl->d_work);
     if (pl->d_totlap) (void)hipFree(pl->d_totlap);
     if (pl->d_glscr) (void)hipFree(pl->d_glscr);
+    if (pl->d_expand) (void)hipFree(pl->d_expand);
     if (pl->d_state) (void)hipFree(pl->d_state);
     if (pl->d_ndone) (void)hipFree(pl->d_ndone);
     if (pl->ev0) (void)hipEventDestroy((hipEvent_t)pl->ev0);
@@ -727,6 +728,30 @@ int launch_points_any(ucf_plan* pl, const ucf_dev_params& dp, int npts, int per_
 }  // namespace
 
 namespace {
+// arbitrary points with the parameter block dp: one abscissa-table row per point, in chunks that keep the table within
+// UCF_TABLE_BYTES
+int batch_points(ucf_plan* pl, const ucf_dev_params& dp, int npts, const double* d_tD, const double* d_rD, const int* d_sv,
+                 double* d_h, double* d_dh, ucf_stats* d_stats, void* stream)
+{
+    const size_t row_bytes = (size_t)pl->D.nabs * 2 * sizeof(double);
+    int chunk = (int)(table_budget() / row_bytes);
+    if (chunk < 1) chunk = 1;
+    if (chunk > npts) chunk = npts;
+    int rc = ensure_work(pl, (size_t)chunk * row_bytes);
+    if (rc) return rc;
+    for (int base = 0; base < npts; base += chunk) {
+        const int n = (npts - base < chunk) ? npts - base : chunk;
+        rc = ucf_faithful::launch_abscissae(dp, n, 1, 1, 0, d_rD + base, d_sv + base, pl->d_work, stream);
+        if (rc) return fail(rc, "abscissa kernel launch failed");
+        rc = launch_points_any(pl, dp, n, 1, 1, 1, 0, d_tD + base, d_rD + base, d_sv + base, d_h + (size_t)base * dp.nz_out,
+                               d_dh + (size_t)base * dp.nz_out, d_stats, stream, nullptr, 1, 0, npts);
+        if (rc) return rc;
+    }
+    return UCF_OK;
+}
+}  // namespace
+
+namespace {
 int grid_device_chunk(ucf_plan* pl, int nt, const double* d_tD, const int* d_sv, int nr, const double* d_rD,
                       int nz, const double* zD, const int* zLay, int nz_out, int z_off, double* d_h, double* d_dh,
                       ucf_stats* d_stats, void* stream);
@@ -767,10 +792,16 @@ int grid_device_chunk(ucf_plan* pl, int nt, const double* d_tD, const int* d_sv,
     const int svmin = j0s[0] < j0s[1] ? j0s[0] : j0s[1];
     const int nsv = (j0s[0] > j0s[1] ? j0s[0] - j0s[1] : j0s[1] - j0s[0]) + 1;     // driver_io.f90:660-664: sv in [min,max]
     const size_t nabs = (size_t)pl->D.nabs;
-    rc = ensure_work(pl, (size_t)nr * nsv * nabs * 2 * sizeof(double));
-    if (rc) return rc;
-    rc = ucf_faithful::launch_abscissae(dp, nr * nsv, 0, nsv, svmin, d_rD, d_sv, pl->d_work, stream);
-    if (rc) return fail(rc, "abscissa kernel launch failed");
+    const int ntiles_ = (nt + UCF_WAVE - 1) / UCF_WAVE;
+    const bool lane_time = nsv == 1 && (double)nt / (64.0 * ntiles_) > (double)pl->D.np / (64.0 * ((pl->D.np + 63) / 64)) && !pl->force_layout0;
+    const bool expand = !lane_time && batch_layout() == 3 && (long long)nt * nr >= 4 * UCF_WAVE && pl->D.np <= UCF_WAVE &&
+                        state_item_bytes(pl, dp) != 0 && !pl->force_layout0;
+    if (!expand) {       // (the expanded grid builds its own table, one row per point)
+        rc = ensure_work(pl, (size_t)nr * nsv * nabs * 2 * sizeof(double));
+        if (rc) return rc;
+        rc = ucf_faithful::launch_abscissae(dp, nr * nsv, 0, nsv, svmin, d_rD, d_sv, pl->d_work, stream);
+        if (rc) return fail(rc, "abscissa kernel launch failed");
+    }
     // lane layout: lane = time (all 64 lanes live, needs one split index for all times) when that fills the
     // wave better than lane = Laplace sample (2M+1 of 64 lanes)
     const int ntiles = (nt + UCF_WAVE - 1) / UCF_WAVE;
@@ -813,6 +844,24 @@ int grid_device_chunk(ucf_plan* pl, int nt, const double* d_tD, const int* d_sv,
         }
         return UCF_OK;
     }
+    // Short time vectors (or several split indices): neither lane = time nor lane = Laplace sample fills the waves.
+    // With enough points the grid is expanded into the point list it stands for and runs lane = point (the outputs
+    // of a grid are in point order already: point = it * nr + ir).
+    const long long np_grid = (long long)nt * nr;
+    if (expand) {
+        if (pl->expand_points < (size_t)np_grid) {
+            if (pl->d_expand) { (void)hipDeviceSynchronize(); (void)hipFree(pl->d_expand); pl->d_expand = nullptr; pl->expand_points = 0; }
+            if (hipMalloc((void**)&pl->d_expand, (size_t)np_grid * (2 * sizeof(double) + sizeof(int))) != hipSuccess)
+                return fail(UCF_ERR_NOMEM, "hipMalloc of the expanded grid (%lld points) failed", np_grid);
+            pl->expand_points = (size_t)np_grid;
+        }
+        double* e_tD = pl->d_expand;
+        double* e_rD = e_tD + np_grid;
+        int* e_sv = (int*)(e_rD + np_grid);
+        rc = ucf_faithful::launch_expand_grid(nt, nr, d_tD, d_sv, d_rD, e_tD, e_rD, e_sv, stream);
+        if (rc) return fail(rc, "grid expansion kernel launch failed");
+        return batch_points(pl, dp, (int)np_grid, e_tD, e_rD, e_sv, d_h, d_dh, d_stats, stream);
+    }
     return launch_points_any(pl, dp, nt * nr, 0, nr, nsv, svmin, d_tD, d_rD, d_sv, d_h, d_dh, d_stats, stream);
 }
 }  // namespace
@@ -843,22 +892,7 @@ int batch_device_chunk(ucf_plan* pl, int npts, const double* d_tD, const double*
     ucf_dev_params dp;
     int rc = fill_call_params(pl, nz, zD, zLay, dp, nz_out, z_off);
     if (rc) return rc;
-    // arbitrary points: one table row per point, in chunks that keep the workspace <= 256 MiB
-    const size_t row_bytes = (size_t)pl->D.nabs * 2 * sizeof(double);
-    int chunk = (int)(table_budget() / row_bytes);
-    if (chunk < 1) chunk = 1;
-    if (chunk > npts) chunk = npts;
-    rc = ensure_work(pl, (size_t)chunk * row_bytes);
-    if (rc) return rc;
-    for (int base = 0; base < npts; base += chunk) {
-        const int n = (npts - base < chunk) ? npts - base : chunk;
-        rc = ucf_faithful::launch_abscissae(dp, n, 1, 1, 0, d_rD + base, d_sv + base, pl->d_work, stream);
-        if (rc) return fail(rc, "abscissa kernel launch failed");
-        rc = launch_points_any(pl, dp, n, 1, 1, 1, 0, d_tD + base, d_rD + base, d_sv + base, d_h + (size_t)base * nz_out,
-                               d_dh + (size_t)base * nz_out, d_stats, stream, nullptr, 1, 0, npts);
-        if (rc) return rc;
-    }
-    return UCF_OK;
+    return batch_points(pl, dp, npts, d_tD, d_rD, d_sv, d_h, d_dh, d_stats, stream);
 }
 }  // namespace
 

@@ -1664,6 +1664,27 @@ static inline size_t point_lds_bytes(const ucf_dev_params& dp, bool resume = fal
 }
 
 #if !UCF_FAST
+// (time, radius) grid -> the point list it stands for, point = it * nr + ir (the grid's own output order)
+__global__ void __launch_bounds__(256)
+expand_grid_kernel(int nt, int nr, const double* __restrict__ tDv, const int* __restrict__ svv, const double* __restrict__ rDv,
+                   double* __restrict__ tDp, double* __restrict__ rDp, int* __restrict__ svp)
+{
+    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= (long long)nt * nr) return;
+    const int it = (int)(q / nr), ir = (int)(q % nr);
+    tDp[q] = tDv[it];
+    svp[q] = svv[it];
+    rDp[q] = rDv[ir];
+}
+int launch_expand_grid(int nt, int nr, const double* d_tD, const int* d_sv, const double* d_rD, double* d_tDp, double* d_rDp,
+                       int* d_svp, void* stream)
+{
+    const long long n = (long long)nt * nr;
+    hipLaunchKernelGGL(expand_grid_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, nt, nr, d_tD, d_sv, d_rD,
+                       d_tDp, d_rDp, d_svp);
+    return hipGetLastError() == hipSuccess ? UCF_OK : UCF_ERR_HIP;
+}
+
 int launch_abscissae(const ucf_dev_params& dp, int nrows, int per_point, int nsv, int svmin, const double* d_rD,
                      const int* d_sv, double* d_tab, void* stream)
 {

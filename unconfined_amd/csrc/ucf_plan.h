@@ -72,6 +72,9 @@ struct ucf_plan {
     // finished J0-interval areas of the resident workgroups: [UCF_GRID_SLOTS][nacc][nz][64] complex
     double* d_glscr;
     size_t glscr_bytes;
+    // a grid expanded into the point list it stands for (small time vectors): tD | rD | sv per point
+    double* d_expand;
+    size_t expand_points;
     // fast flavour: state of every work item between integrate_kernel and point_kernel
     // [items][(R+1+nacc)*nz][64] complex, and the abscissae done per item
     double* d_state;
@@ -85,6 +88,8 @@ namespace ucf_faithful {
 // abscissa tables (shared by both flavours): tab[row][nabs] of (a, a*J0(a*rD))
 int launch_abscissae(const ucf_dev_params& dp, int nrows, int per_point, int nsv, int svmin, const double* d_rD,
                      const int* d_sv, double* d_tab, void* stream);
+int launch_expand_grid(int nt, int nr, const double* d_tD, const int* d_sv, const double* d_rD, double* d_tDp, double* d_rDp,
+                       int* d_svp, void* stream);
 int launch_points(const ucf_dev_params& dp, int npts, int per_point, int nr, int nsv, int svmin, const double* d_tD,
                   const double* d_rD, const int* d_sv, const double* d_tab, double* d_h, double* d_dh,
                   ucf_stats* d_stats, void* stream, double* d_glscr, double* d_state, int* d_ndone,
