@@ -33,7 +33,7 @@ def run(nsets=40, seed=7, verbose=True, judge_above=1e-6, max_judged=6):
             if verbose: print("skip", i, e)
             continue
         D = pf.derived
-        npts = 48
+        npts = int(os.environ.get("UCF_FUZZ_NPTS", "48"))
         tD = 10.0 ** rng.uniform(-2, 5, npts); rD = 10.0 ** rng.uniform(-1, 1, npts)
         zD = np.sort(rng.uniform(0.02, 0.98, 2)); zl = pf.zlay(zD)
         sv = pf.split_vector(tD)
