@@ -1260,7 +1260,9 @@ integrate_kernel(const ucf_dev_params P0, int npts, int per_point, int nr, int n
             aa = nxt;
         }
         if (nz == 1) lds_st(accCur, 0, lane, acc0);       // an unfinished interval travels with the state
-        for (int s = 0; s < (R + 1) * nz; s++) sti[(size_t)s * UCF_WAVE + lane] = lds[s * UCF_WAVE + lane];
+        // (the running area only matters to point_kernel, i.e. when the item is unfinished)
+        const int nslots = (n < nabs) ? (R + 1) * nz : R * nz;
+        for (int s = 0; s < nslots; s++) sti[(size_t)s * UCF_WAVE + lane] = lds[s * UCF_WAVE + lane];
         if (lane == 0) {
             ndone[pt] = n;
             if (n < nabs) todo[1 + atomicAdd(&todo[0], 1)] = pt;      // point_kernel takes it from here
