@@ -1174,7 +1174,8 @@ point_kernel(const ucf_dev_params P0, int npts, int per_point, int nr, int nsv, 
 #ifndef UCF_UNFOLD_WAVES
 #define UCF_UNFOLD_WAVES 4
 #endif
-// WAVES per SIMD the register budget is cut for: 5 when the LDS footprint lets 20 waves share a CU (nz = 1), else 4
+// WAVES per SIMD the register budget is cut for: as many as the LDS footprint admits (6 for nz = 1 at R = 4,
+// fully penetrating; 5; else 4)
 template <int FAMILY, int LAYOUT, int WAVES, bool MULTI, bool FOLD, bool LAY3>
 __global__ void __launch_bounds__(UCF_WAVE, WAVES)
 integrate_kernel(const ucf_dev_params P0, int npts, int per_point, int nr, int nsv, int svmin,
@@ -1770,7 +1771,12 @@ static int launch_transform_(const ucf_dev_params& dp, int nwork, int per_point,
         switch (fam) {
         case 1: if (fold) UCF_LAUNCH_FOLD(1, 4); else UCF_LAUNCH_UNF(1, 4); break;
         case 2:
-            if (fold) { if (w5) UCF_LAUNCH_FOLD(2, UCF_FOLD_WAVES); else UCF_LAUNCH_FOLD(2, 4); }
+            if (fold) {
+                // register budget by the waves the LDS footprint admits per SIMD (measured on C2: 51.6 / 50.3 ms at 5 / 6)
+                if (ilds * 24 <= 160 * 1024) UCF_LAUNCH_FOLD(2, 6);
+                else if (w5) UCF_LAUNCH_FOLD(2, UCF_FOLD_WAVES);
+                else UCF_LAUNCH_FOLD(2, 4);
+            }
             else UCF_LAUNCH_UNF(2, UCF_UNFOLD_WAVES);   // the screen terms need the registers: 5 waves/SIMD would spill ~50 VGPRs
             break;
         case 4: if (fold) UCF_LAUNCH_FOLD(4, 4); else UCF_LAUNCH_UNF(4, 4); break;
