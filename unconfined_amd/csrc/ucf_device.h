@@ -1204,6 +1204,8 @@ integrate_kernel(const ucf_dev_params P0, int npts, int per_point, int nr, int n
         const double tee = 2.0 * tD;                                                            // driver.f90:106,217
         const double sigma = P.alpha - P.logtol / (2.0 * tee);                                  // invlap.f90:165
         const cplx p = cmake(sigma, UCF_PI * W.mlap / tee);                                     // invlap.f90:168
+        // (the pumping-schedule multiplier lapTime(p) is constant over the abscissae: the sums are formed without it and
+        //  scaled when they leave the kernel -- one complex product per sample less)
         const cplx lt = lap_time(P, p);
         const lane_consts LC = make_lane_consts(P, p, lt);
         double2* __restrict__ sti = state + (size_t)pt * state_slots(P0) * UCF_WAVE;
@@ -1228,8 +1230,8 @@ integrate_kernel(const ucf_dev_params P0, int npts, int per_point, int nr, int n
             int tz = __builtin_ctz(n1);
             if (tz > R - 1) tz = R - 1;
             for (int z = 0; z < nz; z++) {
-                // val = a*J0(a rD) * f(a,p,z) * lapTime(p)                                      (lhs.f90:118)
-                const cplx val = cmul(rscale(aa.y, fast_sample_z<FAMILY, FOLD, LAY3>(P, F, z)), lt);
+                // val = a*J0(a rD) * f(a,p,z) [* lapTime(p): at the end]                         (lhs.f90:118)
+                const cplx val = rscale(aa.y, fast_sample_z<FAMILY, FOLD, LAY3>(P, F, z));
                 if (ts) {
                     // tanh-sinh on [0, arg]: abscissa n+1 belongs to level j when 2^(R-j) divides it  (driver.f90:129-157)
                     for (int sh = 0; sh <= tz; sh++) {
@@ -1250,7 +1252,7 @@ integrate_kernel(const ucf_dev_params P0, int npts, int per_point, int nr, int n
                 const double hib = P.j0z[sv + jj] / rD;
                 const double hw = (hib - lob) / 2.0;
                 for (int z = 0; z < nz; z++) {
-                    const cplx ar = rscale(hw, nz == 1 ? acc0 : lds_ld(accCur, z, lane));
+                    const cplx ar = cmul(rscale(hw, nz == 1 ? acc0 : lds_ld(accCur, z, lane)), lt);
                     areas[(size_t)(jj * nz + z) * UCF_WAVE + lane] = make_double2(ar.re, ar.im);
                     if (nz != 1) lds_st(accCur, z, lane, cmake(0.0, 0.0));
                 }
@@ -1263,7 +1265,10 @@ integrate_kernel(const ucf_dev_params P0, int npts, int per_point, int nr, int n
         if (nz == 1) lds_st(accCur, 0, lane, acc0);       // an unfinished interval travels with the state
         // (the running area only matters to point_kernel, i.e. when the item is unfinished)
         const int nslots = (n < nabs) ? (R + 1) * nz : R * nz;
-        for (int s = 0; s < nslots; s++) sti[(size_t)s * UCF_WAVE + lane] = lds[s * UCF_WAVE + lane];
+        for (int s = 0; s < nslots; s++) {
+            const cplx v = cmul(lds_ld(lds, s, lane), lt);
+            sti[(size_t)s * UCF_WAVE + lane] = make_double2(v.re, v.im);
+        }
         if (lane == 0) {
             ndone[pt] = n;
             if (n < nabs) todo[1 + atomicAdd(&todo[0], 1)] = pt;      // point_kernel takes it from here
