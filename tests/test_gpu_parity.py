@@ -464,9 +464,9 @@ def test_pipeline_knobs_do_not_change_results(tmp_path):
         a, b = ref[k], res["lane_sample"][k]
         assert np.array_equal(np.isnan(a), np.isnan(b)), k
         if k.endswith("_hb") or k.startswith("multi_h") or k.startswith("single_h"):
-            sel = (slice(None), slice(1, None)) if k.endswith("_hb") and False else slice(None)
             fin = np.isfinite(a)
-            assert rel_err(a[fin], b[fin], 1e-6).max() < 1e-6, k
+            scale = np.abs(b[fin]).max()
+            assert (np.abs(a[fin] - b[fin]) / np.maximum(np.abs(b[fin]), 1e-4 * scale)).max() < 1e-6, k
     # grid (lane = time) and batch (lane = Laplace sample) agree to rounding of the fast flavour's contractions
     for name in ("c2_neuman74_fullpen", "neuman74_partpen"):
         hg = ref[name + "_h"][::2]; hb = ref[name + "_hb"].reshape(hg.shape)

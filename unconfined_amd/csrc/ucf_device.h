@@ -1206,7 +1206,7 @@ integrate_kernel(const ucf_dev_params P0, int npts, int per_point, int nr, int n
         const cplx p = cmake(sigma, UCF_PI * W.mlap / tee);                                     // invlap.f90:168
         // (the pumping-schedule multiplier lapTime(p) is constant over the abscissae: the sums are formed without it and
         //  scaled when they leave the kernel -- one complex product per sample less)
-        const cplx lt = lap_time(P, p);
+        const cplx lt = cscale(lap_time(P, p), fast_scale<FAMILY>(P));      // and the constants the evaluators leave out
         const lane_consts LC = make_lane_consts(P, p, lt);
         double2* __restrict__ sti = state + (size_t)pt * state_slots(P0) * UCF_WAVE;
         double2* __restrict__ areas = sti + (size_t)(R + 1) * nz * UCF_WAVE;
@@ -1559,7 +1559,8 @@ samples_kernel(const ucf_dev_params P, int n_a, const double* __restrict__ av, d
     for (int z = 0; z < P.nz; z++) {
         cplx f;
 #if UCF_FAST
-        if (fast) f = fast_sample_z<(FAMILY == 1 || FAMILY == 2 || FAMILY == 4) ? FAMILY : 1>(P, F, z);
+        if (fast) f = cscale(fast_sample_z<(FAMILY == 1 || FAMILY == 2 || FAMILY == 4) ? FAMILY : 1>(P, F, z),
+                             fast_scale<(FAMILY == 1 || FAMILY == 2 || FAMILY == 4) ? FAMILY : 1>(P));
         else
 #endif
             f = sample_z<FAMILY>(P, S, z);

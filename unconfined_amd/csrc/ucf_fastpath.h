@@ -161,6 +161,16 @@ struct fast_common {
     bool any_small, any_large;   // wave-uniform: some lane on the cosh/sinh form, some lane on the exponential form
 };
 
+// Every fast sample is linear in theis(a, p) = 2/(p + a^2) and, for the Hantush-based models, carries the factor
+// 1/bD (:200): both constants are left out of the evaluators and applied once to whatever the samples were summed
+// into (integrate_kernel: with lapTime(p), when the sums leave the kernel).  fast_sample_z() * fast_scale() is the
+// reference's sample.
+template <int FAMILY>
+UCF_DEV double fast_scale(const ucf_dev_params& P)
+{
+    return (FAMILY == 2 && P.model == 4) ? 2.0 : 2.0 * P.inv_bD;
+}
+
 // theta and eta of this abscissa.  Returns false (for this lane) if the fast evaluation is not applicable:
 // a cosh/sinh could overflow, or the argument of a sin/cos (|Im eta| times a factor <= 1) leaves the range of
 // the two-stage Cody-Waite reduction.
@@ -171,7 +181,7 @@ UCF_DEV bool fast_eta(const ucf_dev_params& P, const lane_consts& L, double a, f
     const cplx q = caddr(L.p, a2);
     {
         const double r = fast_rcp(q.re * q.re + q.im * q.im);
-        S.th = cmake(2.0 * q.re * r, -(2.0 * q.im * r));                                        // :122-131
+        S.th = cmake(q.re * r, -(q.im * r));                      // HALF of theis = 2/q (:122-131): see fast_scale()
     }
     {   // eta = sqrt(q/kappa), Re q > 0                                                         (:69,172)
         const double qr = q.re * P.inv_kappa, qi = q.im * P.inv_kappa;
@@ -227,7 +237,7 @@ UCF_DEV void fast_common_terms(const ucf_dev_params& P, const lane_consts& L, do
         }
         if (FAMILY != 1) {
             // water-table value: hantush at zD = 1 (layer 3): g1 - g2                          (:81,162-170,196)
-            S.top = S.top3 = cscale(S.th, P.inv_bD);
+            S.top = S.top3 = S.th;
             if (!(z1 && z2)) {
                 if (need_lay12) {
                     cplx g1;
@@ -235,7 +245,7 @@ UCF_DEV void fast_common_terms(const ucf_dev_params& P, const lane_consts& L, do
                     else if (P.share_g1top) g1 = pcosh(pd);
                     else { const double c = P.dD1 - 1.0; g1 = pcosh(prim(S.eta.re * c, S.eta.im * c)); }
                     const cplx udp = csub(g1, cmul(cadd(cmul(S.ff1, S.che), S.ff2), S.inv_she));
-                    S.top = cscale(cmul(udp, S.th), P.inv_bD);                                  // :200
+                    S.top = cmul(udp, S.th);                                                    // :200 (x fast_scale)
                 }
                 if (need_lay3) {
                     // For a depth above the screen top the rounding noise of that form matters (two terms of size
@@ -253,7 +263,7 @@ UCF_DEV void fast_common_terms(const ucf_dev_params& P, const lane_consts& L, do
                         else sd1 = psinh(prim(x1, S.eta.im * P.dD1));
                     }
                     const cplx udp = cmul(z2 ? sd1 : csub(sd1, S.ff2), S.inv_she);
-                    S.top3 = cscale(cmul(udp, S.th), P.inv_bD);
+                    S.top3 = cmul(udp, S.th);
                 }
             }
         }
@@ -346,7 +356,7 @@ UCF_DEV cplx fast_hantush_z(const ucf_dev_params& P, const fast_common& S, doubl
         cplx f2c = cmake(0.0, 0.0);
         if (!z2) f2c = cmul(S.ff2, pcosh(p1z));                  // sinh(eta lD1) cosh(eta (1 - zD))
         if (lay == 2 || !LAY3) {
-            if (z1 && z2) return cscale(S.th, P.inv_bD);                                        // g2 = 0: udp = 1
+            if (z1 && z2) return S.th;                                                          // g2 = 0: udp = 1
             cplx num = f2c;
             if (!z1) num = cadd(cmul(S.ff1, chz), f2c);
             g2 = cmul(num, S.inv_she);                                                          // :179-180
@@ -364,7 +374,7 @@ UCF_DEV cplx fast_hantush_z(const ucf_dev_params& P, const fast_common& S, doubl
             udp = cmul(num, S.inv_she);
         }
     }
-    return cscale(cmul(udp, S.th), P.inv_bD);                                                   // :200
+    return cmul(udp, S.th);                                                                     // :200 (x fast_scale)
 }
 
 template <int FAMILY, bool FOLD = false, bool LAY3 = true>
