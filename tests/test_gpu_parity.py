@@ -471,7 +471,8 @@ def test_pipeline_knobs_do_not_change_results(tmp_path):
     for name in ("c2_neuman74_fullpen", "neuman74_partpen"):
         hg = ref[name + "_h"][::2]; hb = ref[name + "_hb"].reshape(hg.shape)
         assert np.array_equal(np.isnan(hg), np.isnan(hb))
-        assert rel_err(hg[:, 1:], hb[:, 1:], 1e-6).max() < 1e-6, name      # (column 0 is the overflow regime)
+        a_, b_ = hg[:, 1:], hb[:, 1:]                                        # (column 0 is the overflow regime)
+        assert (np.abs(a_ - b_) / np.maximum(np.abs(b_), 1e-4 * np.abs(b_).max())).max() < 1e-6, name
 
 
 _LAYOUT_SCRIPT = r"""

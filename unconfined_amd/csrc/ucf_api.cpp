@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <algorithm>
 #include <vector>
 
 #include "ucf_plan.h"
@@ -921,6 +922,21 @@ int ucf_drawdown_batch(ucf_plan* pl, int npts, const double* tD, const double* r
     if (b_t.alloc(nb) || b_r.alloc(nb) || b_s.alloc(sizeof(int) * (size_t)npts) || b_h.alloc(nb * nz) ||
         b_d.alloc(nb * nz) || b_st.alloc(sizeof(ucf_stats)))
         return fail(UCF_ERR_NOMEM, "device allocation failed for %d points", npts);
+    // A long list runs with lane = point: the 64 points of a wave should be neighbours in radius, because the wave
+    // leaves the fast evaluators at the first lane that must (small radii reach the overflow regime early).  The list
+    // is evaluated in order of radius and the results are put back in the caller's order.
+    std::vector<int> perm;
+    std::vector<double> tS, rS, hS, dS;
+    std::vector<int> sS;
+    const bool sorted = npts >= 4 * UCF_WAVE && batch_layout() == 3;
+    if (sorted) {
+        perm.resize(npts);
+        for (int i = 0; i < npts; i++) perm[i] = i;
+        std::stable_sort(perm.begin(), perm.end(), [&](int x, int y) { return rD[x] < rD[y]; });
+        tS.resize(npts); rS.resize(npts); sS.resize(npts);
+        for (int i = 0; i < npts; i++) { tS[i] = tD[perm[i]]; rS[i] = rD[perm[i]]; sS[i] = sv[perm[i]]; }
+        tD = tS.data(); rD = rS.data(); sv = sS.data();
+    }
     HIP_TRY(hipMemcpy(b_t.p, tD, nb, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(b_r.p, rD, nb, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(b_s.p, sv, sizeof(int) * (size_t)npts, hipMemcpyHostToDevice));
@@ -929,8 +945,19 @@ int ucf_drawdown_batch(ucf_plan* pl, int npts, const double* tD, const double* r
                                    zLay, (double*)b_h.p, (double*)b_d.p, stats ? (ucf_stats*)b_st.p : nullptr, nullptr);
     if (rc) return rc;
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(h, b_h.p, nb * nz, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(dh, b_d.p, nb * nz, hipMemcpyDeviceToHost));
+    if (sorted) {
+        hS.resize((size_t)npts * nz); dS.resize((size_t)npts * nz);
+        HIP_TRY(hipMemcpy(hS.data(), b_h.p, nb * nz, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(dS.data(), b_d.p, nb * nz, hipMemcpyDeviceToHost));
+        for (int i = 0; i < npts; i++)
+            for (int z = 0; z < nz; z++) {
+                h[(size_t)perm[i] * nz + z] = hS[(size_t)i * nz + z];
+                dh[(size_t)perm[i] * nz + z] = dS[(size_t)i * nz + z];
+            }
+    } else {
+        HIP_TRY(hipMemcpy(h, b_h.p, nb * nz, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(dh, b_d.p, nb * nz, hipMemcpyDeviceToHost));
+    }
     if (stats) HIP_TRY(hipMemcpy(stats, b_st.p, sizeof(ucf_stats), hipMemcpyDeviceToHost));
     return UCF_OK;
 }
@@ -977,6 +1004,28 @@ int ucf_drawdown_multi(ucf_plan* const* plans, int nplans, int npts, const doubl
     if (!t || !r || !z || !h || !dh) return fail(UCF_ERR_BAD_ARGUMENT, "NULL array");
     for (int k = 0; k < nplans; k++) if (!plans[k]) return fail(UCF_ERR_BAD_ARGUMENT, "plans[%d] is NULL", k);
     const size_t np_ = (size_t)npts, tot = (size_t)nplans * np_;
+    // the observation points are evaluated in order of radius (see ucf_drawdown_batch) and put back at the end
+    std::vector<int> perm(npts);
+    for (int i = 0; i < npts; i++) perm[i] = i;
+    std::stable_sort(perm.begin(), perm.end(), [&](int x, int y) { return r[x] < r[y]; });
+    std::vector<double> t_s(npts), r_s(npts);
+    for (int i = 0; i < npts; i++) { t_s[i] = t[perm[i]]; r_s[i] = r[perm[i]]; }
+    double* const h_user = h;
+    double* const dh_user = dh;
+    std::vector<double> h_tmp(tot * nz), dh_tmp(tot * nz);
+    t = t_s.data(); r = r_s.data(); h = h_tmp.data(); dh = dh_tmp.data();
+    struct unsort_at_exit {
+        const std::vector<int>& perm; size_t np_, tot; int nplans, nz; const double* hs; const double* ds; double* h; double* dh; bool armed;
+        ~unsort_at_exit() {
+            if (!armed) return;
+            for (int k = 0; k < nplans; k++)
+                for (size_t i = 0; i < np_; i++)
+                    for (int z = 0; z < nz; z++) {
+                        h[(k * np_ + perm[i]) * nz + z] = hs[(k * np_ + i) * nz + z];
+                        dh[(k * np_ + perm[i]) * nz + z] = ds[(k * np_ + i) * nz + z];
+                    }
+        }
+    } unsort{perm, np_, tot, nplans, nz, h_tmp.data(), dh_tmp.data(), h_user, dh_user, true};
     // host staging: per plan tD, rD, sv
     std::vector<double> tD(tot), rD(tot), zD((size_t)nplans * nz);
     std::vector<int> sv(tot), zl((size_t)nplans * nz);
