@@ -509,6 +509,28 @@ def test_point_list_layouts_same_bits_faithful(tmp_path):
         assert np.array_equal(res["point"][k], res["sample"][k], equal_nan=True), k
 
 
+def test_device_entry_orders_by_radius(engine):
+    """ucf_drawdown_batch_device on device-resident, unordered points (radii from the overflow regime up): the library
+    orders them by radius on the device; same bits as the host entry, which orders them on the host"""
+    import torch
+    dk, ts, P = load_deck("neuman74_partpen")
+    plan = engine.Plan(P, mode="fast")
+    rng = np.random.default_rng(9)
+    n = 1500
+    tD = 10.0 ** rng.uniform(-1, 4, n); rD = 10.0 ** rng.uniform(np.log10(0.03), 1, n); sv = plan.split_vector(tD)
+    zD = np.array([0.4, 0.93]); zl = plan.zlay(zD)
+    h0, dh0 = plan.drawdown(tD, rD, sv, zD, zl)
+    dev = torch.device("cuda:0")
+    d_t = torch.tensor(tD, device=dev); d_r = torch.tensor(rD, device=dev); d_s = torch.tensor(sv, dtype=torch.int32, device=dev)
+    d_h = torch.zeros(n, 2, dtype=torch.float64, device=dev); d_dh = torch.zeros_like(d_h)
+    plan.drawdown_device(n, d_t.data_ptr(), d_r.data_ptr(), d_s.data_ptr(), zD, zl, d_h.data_ptr(), d_dh.data_ptr(),
+                         stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_h.cpu().numpy(), h0, equal_nan=True)
+    assert np.array_equal(d_dh.cpu().numpy(), dh0, equal_nan=True)
+    assert np.isfinite(h0).mean() > 0.9
+
+
 def test_parameter_batched_sweep(engine):
     """f4: the same observation points under 12 parameter sets in one call == 12 single-plan calls"""
     from unconfined_amd.abi import params_from_deck

@@ -17,6 +17,7 @@
 #include <new>
 #include <algorithm>
 #include <vector>
+#include <rocprim/device/device_radix_sort.hpp>   // (after <cstring>: its headers use memset on the host)
 
 #include "ucf_plan.h"
 
@@ -442,6 +443,7 @@ void ucf_plan_destroy(ucf_plan* pl)
     if (pl->d_totlap) (void)hipFree(pl->d_totlap);
     if (pl->d_glscr) (void)hipFree(pl->d_glscr);
     if (pl->d_expand) (void)hipFree(pl->d_expand);
+    if (pl->d_sort) (void)hipFree(pl->d_sort);
     if (pl->d_state) (void)hipFree(pl->d_state);
     if (pl->d_ndone) (void)hipFree(pl->d_ndone);
     if (pl->ev0) (void)hipEventDestroy((hipEvent_t)pl->ev0);
@@ -867,6 +869,82 @@ int grid_device_chunk(ucf_plan* pl, int nt, const double* d_tD, const int* d_sv,
 }
 }  // namespace
 
+namespace {
+__global__ void iota_kernel(int n, int* v)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] = i;
+}
+__global__ void gather_points_kernel(int n, const int* __restrict__ perm, const double* __restrict__ tD, const int* __restrict__ sv,
+                                     double* __restrict__ tDs, int* __restrict__ svs)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { tDs[i] = tD[perm[i]]; svs[i] = sv[perm[i]]; }
+}
+__global__ void scatter_results_kernel(int n, int nz, const int* __restrict__ perm, const double* __restrict__ hs,
+                                       const double* __restrict__ dhs, double* __restrict__ h, double* __restrict__ dh)
+{
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long long)n * nz) return;
+    const int i = (int)(e / nz), z = (int)(e % nz);
+    h[(size_t)perm[i] * nz + z] = hs[e];
+    dh[(size_t)perm[i] * nz + z] = dhs[e];
+}
+
+int batch_device_all_depths(ucf_plan* pl, int npts, const double* d_tD, const double* d_rD, const int* d_sv,
+                            int nz, const double* zD, const int* zLay, double* d_h, double* d_dh, ucf_stats* d_stats, void* stream)
+{
+    const int zc = z_chunk(pl);
+    for (int z0 = 0; z0 < nz; z0 += zc) {
+        const int n = (nz - z0 < zc) ? nz - z0 : zc;
+        int rc = batch_device_chunk(pl, npts, d_tD, d_rD, d_sv, n, zD + z0, zLay + z0, nz, z0, d_h, d_dh, d_stats, stream);
+        if (rc) return rc;
+    }
+    return UCF_OK;
+}
+
+// presorted: the caller (ucf_drawdown_batch) already put the points in order of radius
+int batch_device_impl(ucf_plan* pl, int npts, const double* d_tD, const double* d_rD, const int* d_sv,
+                      int nz, const double* zD, const int* zLay, double* d_h, double* d_dh, ucf_stats* d_stats, void* stream,
+                      bool presorted)
+{
+    if (presorted || npts < 4 * UCF_WAVE || batch_layout() != 3)
+        return batch_device_all_depths(pl, npts, d_tD, d_rD, d_sv, nz, zD, zLay, d_h, d_dh, d_stats, stream);
+    // lane = point wants the 64 points of a wave to be neighbours in radius (see ucf_drawdown_batch): sort by radius on
+    // the device (rocPRIM radix sort of (rD, index)), evaluate, scatter the results back to the caller's order
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n = (size_t)npts;
+    size_t temp_bytes = 0;
+    if (rocprim::radix_sort_pairs(nullptr, temp_bytes, d_rD, (double*)nullptr, (int*)nullptr, (int*)nullptr, n, 0, 64, s) != hipSuccess)
+        return fail(UCF_ERR_HIP, "rocprim::radix_sort_pairs (size query) failed");
+    // one allocation: keys_out | tD_s | h_s | dh_s | idx_in | idx_out | sv_s | sort temp
+    const size_t off_keys = 0, off_t = off_keys + n * 8, off_h = off_t + n * 8, off_d = off_h + n * nz * 8, off_i0 = off_d + n * nz * 8,
+                 off_i1 = off_i0 + n * 4, off_sv = off_i1 + n * 4, off_tmp = (off_sv + n * 4 + 255) / 256 * 256, total = off_tmp + temp_bytes;
+    if (pl->sort_bytes < total) {
+        if (pl->d_sort) { (void)hipDeviceSynchronize(); (void)hipFree(pl->d_sort); pl->d_sort = nullptr; pl->sort_bytes = 0; }
+        if (hipMalloc((void**)&pl->d_sort, total) != hipSuccess) return fail(UCF_ERR_NOMEM, "hipMalloc of %zu sort-workspace bytes failed", total);
+        pl->sort_bytes = total;
+    }
+    char* base = (char*)pl->d_sort;
+    double* keys = (double*)(base + off_keys);
+    double* tDs = (double*)(base + off_t);
+    double* hs = (double*)(base + off_h);
+    double* dhs = (double*)(base + off_d);
+    int* i0 = (int*)(base + off_i0);
+    int* i1 = (int*)(base + off_i1);
+    int* svs = (int*)(base + off_sv);
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(iota_kernel, dim3(nb), dim3(256), 0, s, npts, i0);
+    if (rocprim::radix_sort_pairs(base + off_tmp, temp_bytes, d_rD, keys, i0, i1, n, 0, 64, s) != hipSuccess)
+        return fail(UCF_ERR_HIP, "rocprim::radix_sort_pairs failed");
+    hipLaunchKernelGGL(gather_points_kernel, dim3(nb), dim3(256), 0, s, npts, i1, d_tD, d_sv, tDs, svs);
+    int rc = batch_device_all_depths(pl, npts, tDs, keys, svs, nz, zD, zLay, hs, dhs, d_stats, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(scatter_results_kernel, dim3((unsigned)((n * nz + 255) / 256)), dim3(256), 0, s, npts, nz, i1, hs, dhs, d_h, d_dh);
+    return hipGetLastError() == hipSuccess ? UCF_OK : fail(UCF_ERR_HIP, "sort helper kernels failed");
+}
+}  // namespace
+
 int ucf_drawdown_batch_device(ucf_plan* pl, int npts, const double* d_tD, const double* d_rD, const int* d_sv,
                               int nz, const double* zD, const int* zLay, double* d_h, double* d_dh,
                               ucf_stats* d_stats, void* stream)
@@ -876,13 +954,7 @@ int ucf_drawdown_batch_device(ucf_plan* pl, int npts, const double* d_tD, const 
     if (nz < 1) return fail(UCF_ERR_BAD_ARGUMENT, "nz < 1");
     if (npts == 0) return UCF_OK;
     if (!d_tD || !d_rD || !d_sv || !d_h || !d_dh || !zD || !zLay) return fail(UCF_ERR_BAD_ARGUMENT, "NULL array");
-    const int zc = z_chunk(pl);
-    for (int z0 = 0; z0 < nz; z0 += zc) {
-        const int n = (nz - z0 < zc) ? nz - z0 : zc;
-        int rc = batch_device_chunk(pl, npts, d_tD, d_rD, d_sv, n, zD + z0, zLay + z0, nz, z0, d_h, d_dh, d_stats, stream);
-        if (rc) return rc;
-    }
-    return UCF_OK;
+    return batch_device_impl(pl, npts, d_tD, d_rD, d_sv, nz, zD, zLay, d_h, d_dh, d_stats, stream, false);
 }
 
 namespace {
@@ -941,8 +1013,9 @@ int ucf_drawdown_batch(ucf_plan* pl, int npts, const double* tD, const double* r
     HIP_TRY(hipMemcpy(b_r.p, rD, nb, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(b_s.p, sv, sizeof(int) * (size_t)npts, hipMemcpyHostToDevice));
     HIP_TRY(hipMemset(b_st.p, 0, sizeof(ucf_stats)));
-    rc = ucf_drawdown_batch_device(pl, npts, (const double*)b_t.p, (const double*)b_r.p, (const int*)b_s.p, nz, zD,
-                                   zLay, (double*)b_h.p, (double*)b_d.p, stats ? (ucf_stats*)b_st.p : nullptr, nullptr);
+    if (nz < 1 || !zD || !zLay) return fail(UCF_ERR_BAD_ARGUMENT, "bad depths");
+    rc = batch_device_impl(pl, npts, (const double*)b_t.p, (const double*)b_r.p, (const int*)b_s.p, nz, zD,
+                           zLay, (double*)b_h.p, (double*)b_d.p, stats ? (ucf_stats*)b_st.p : nullptr, nullptr, true);
     if (rc) return rc;
     HIP_TRY(hipDeviceSynchronize());
     if (sorted) {

@@ -75,6 +75,9 @@ struct ucf_plan {
     // a grid expanded into the point list it stands for (small time vectors): tD | rD | sv per point
     double* d_expand;
     size_t expand_points;
+    // device-side ordering of a point list by radius (ucf_drawdown_batch_device): keys, permutation, staged inputs/outputs
+    void* d_sort;
+    size_t sort_bytes;
     // fast flavour: state of every work item between integrate_kernel and point_kernel
     // [items][(R+1+nacc)*nz][64] complex, and the abscissae done per item
     double* d_state;
