@@ -761,6 +761,9 @@ int grid_device_chunk(ucf_plan* pl, int nt, const double* d_tD, const int* d_sv,
 int batch_device_chunk(ucf_plan* pl, int npts, const double* d_tD, const double* d_rD, const int* d_sv,
                        int nz, const double* zD, const int* zLay, int nz_out, int z_off, double* d_h, double* d_dh,
                        ucf_stats* d_stats, void* stream);
+int batch_device_impl(ucf_plan* pl, int npts, const double* d_tD, const double* d_rD, const int* d_sv,
+                      int nz, const double* zD, const int* zLay, double* d_h, double* d_dh, ucf_stats* d_stats, void* stream,
+                      bool presorted);
 }
 
 int ucf_drawdown_grid_device(ucf_plan* pl, int nt, const double* d_tD, const int* d_sv, int nr, const double* d_rD,
@@ -773,6 +776,33 @@ int ucf_drawdown_grid_device(ucf_plan* pl, int nt, const double* d_tD, const int
     if (nt == 0 || nr == 0) return UCF_OK;
     if ((long long)nt * nr > 0x7fffffffLL) return fail(UCF_ERR_BAD_ARGUMENT, "grid larger than 2^31-1 points: split it");
     if (!d_tD || !d_rD || !d_sv || !d_h || !d_dh || !zD || !zLay) return fail(UCF_ERR_BAD_ARGUMENT, "NULL array");
+    {
+        // Short time vectors (or several split indices): neither lane = time nor lane = Laplace sample fills the waves.
+        // With enough points the grid is expanded into the point list it stands for and runs lane = point, in order of
+        // radius like every long list (the outputs of a grid are in point order already: point = it * nr + ir).
+        const int* j0s = pl->P.j0s;
+        const int nsv = (j0s[0] > j0s[1] ? j0s[0] - j0s[1] : j0s[1] - j0s[0]) + 1;
+        const int ntiles_ = (nt + UCF_WAVE - 1) / UCF_WAVE;
+        const bool lane_time = nsv == 1 && (double)nt / (64.0 * ntiles_) > (double)pl->D.np / (64.0 * ((pl->D.np + 63) / 64)) && !pl->force_layout0;
+        ucf_dev_params one = pl->dev;
+        one.nz = 1;
+        const long long np_grid = (long long)nt * nr;
+        if (!lane_time && batch_layout() == 3 && np_grid >= 4 * UCF_WAVE && pl->D.np <= UCF_WAVE && state_item_bytes(pl, one) != 0 &&
+            !pl->force_layout0) {
+            if (pl->expand_points < (size_t)np_grid) {
+                if (pl->d_expand) { (void)hipDeviceSynchronize(); (void)hipFree(pl->d_expand); pl->d_expand = nullptr; pl->expand_points = 0; }
+                if (hipMalloc((void**)&pl->d_expand, (size_t)np_grid * (2 * sizeof(double) + sizeof(int))) != hipSuccess)
+                    return fail(UCF_ERR_NOMEM, "hipMalloc of the expanded grid (%lld points) failed", np_grid);
+                pl->expand_points = (size_t)np_grid;
+            }
+            double* e_tD = pl->d_expand;
+            double* e_rD = e_tD + np_grid;
+            int* e_sv = (int*)(e_rD + np_grid);
+            int rc = ucf_faithful::launch_expand_grid(nt, nr, d_tD, d_sv, d_rD, e_tD, e_rD, e_sv, stream);
+            if (rc) return fail(rc, "grid expansion kernel launch failed");
+            return batch_device_impl(pl, (int)np_grid, e_tD, e_rD, e_sv, nz, zD, zLay, d_h, d_dh, d_stats, stream, false);
+        }
+    }
     // depths in chunks that fit the wave's LDS budget; each chunk is its own launch sequence on the stream
     const int zc = z_chunk(pl);
     for (int z0 = 0; z0 < nz; z0 += zc) {
@@ -797,14 +827,11 @@ int grid_device_chunk(ucf_plan* pl, int nt, const double* d_tD, const int* d_sv,
     const size_t nabs = (size_t)pl->D.nabs;
     const int ntiles_ = (nt + UCF_WAVE - 1) / UCF_WAVE;
     const bool lane_time = nsv == 1 && (double)nt / (64.0 * ntiles_) > (double)pl->D.np / (64.0 * ((pl->D.np + 63) / 64)) && !pl->force_layout0;
-    const bool expand = !lane_time && batch_layout() == 3 && (long long)nt * nr >= 4 * UCF_WAVE && pl->D.np <= UCF_WAVE &&
-                        state_item_bytes(pl, dp) != 0 && !pl->force_layout0;
-    if (!expand) {       // (the expanded grid builds its own table, one row per point)
-        rc = ensure_work(pl, (size_t)nr * nsv * nabs * 2 * sizeof(double));
-        if (rc) return rc;
-        rc = ucf_faithful::launch_abscissae(dp, nr * nsv, 0, nsv, svmin, d_rD, d_sv, pl->d_work, stream);
-        if (rc) return fail(rc, "abscissa kernel launch failed");
-    }
+    (void)lane_time;
+    rc = ensure_work(pl, (size_t)nr * nsv * nabs * 2 * sizeof(double));
+    if (rc) return rc;
+    rc = ucf_faithful::launch_abscissae(dp, nr * nsv, 0, nsv, svmin, d_rD, d_sv, pl->d_work, stream);
+    if (rc) return fail(rc, "abscissa kernel launch failed");
     // lane layout: lane = time (all 64 lanes live, needs one split index for all times) when that fills the
     // wave better than lane = Laplace sample (2M+1 of 64 lanes)
     const int ntiles = (nt + UCF_WAVE - 1) / UCF_WAVE;
@@ -846,24 +873,6 @@ int grid_device_chunk(ucf_plan* pl, int nt, const double* d_tD, const int* d_sv,
             if (rc) return fail(rc, "kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
         }
         return UCF_OK;
-    }
-    // Short time vectors (or several split indices): neither lane = time nor lane = Laplace sample fills the waves.
-    // With enough points the grid is expanded into the point list it stands for and runs lane = point (the outputs
-    // of a grid are in point order already: point = it * nr + ir).
-    const long long np_grid = (long long)nt * nr;
-    if (expand) {
-        if (pl->expand_points < (size_t)np_grid) {
-            if (pl->d_expand) { (void)hipDeviceSynchronize(); (void)hipFree(pl->d_expand); pl->d_expand = nullptr; pl->expand_points = 0; }
-            if (hipMalloc((void**)&pl->d_expand, (size_t)np_grid * (2 * sizeof(double) + sizeof(int))) != hipSuccess)
-                return fail(UCF_ERR_NOMEM, "hipMalloc of the expanded grid (%lld points) failed", np_grid);
-            pl->expand_points = (size_t)np_grid;
-        }
-        double* e_tD = pl->d_expand;
-        double* e_rD = e_tD + np_grid;
-        int* e_sv = (int*)(e_rD + np_grid);
-        rc = ucf_faithful::launch_expand_grid(nt, nr, d_tD, d_sv, d_rD, e_tD, e_rD, e_sv, stream);
-        if (rc) return fail(rc, "grid expansion kernel launch failed");
-        return batch_points(pl, dp, (int)np_grid, e_tD, e_rD, e_sv, d_h, d_dh, d_stats, stream);
     }
     return launch_points_any(pl, dp, nt * nr, 0, nr, nsv, svmin, d_tD, d_rD, d_sv, d_h, d_dh, d_stats, stream);
 }
