@@ -509,6 +509,38 @@ def test_point_list_layouts_same_bits_faithful(tmp_path):
         assert np.array_equal(res["point"][k], res["sample"][k], equal_nan=True), k
 
 
+def test_plan_update_equals_fresh_plan(engine):
+    """ucf_plan_update: an existing plan given new parameters computes what a fresh plan computes, bit for bit
+    (water-table model, the finite-difference closure with its parameter-dependent table, a pumping schedule); a
+    change of the numerical settings is refused"""
+    from unconfined_amd.abi import params_from_deck
+    from unconfined_amd.lib import UcfError
+    t = 10.0 ** np.linspace(-1, 4, 40); r = np.full(40, 85.1); r[::4] = 20.0
+    for name in ("neuman74_partpen", "mishra_fd30", "neuman_sched2"):
+        dk, ts, P0 = load_deck(name)
+        for mode in MODES:
+            plan = engine.Plan(P0, mode=mode)
+            for i in range(3):
+                d = dk.replace(Kr=dk.Kr * (0.5 + 0.4 * i), Sy=dk.Sy * (0.7 + 0.1 * i), kappa=dk.kappa * (0.6 + 0.3 * i),
+                               ak=dk.ak * (1.0 + 0.2 * i), Q=dk.Q * (1 + i))
+                Pn = params_from_deck(d)
+                plan.update(Pn)
+                fresh = engine.Plan(Pn, mode=mode)
+                D = fresh.derived
+                assert plan.derived.Tc == D.Tc and plan.derived.Hc == D.Hc
+                tD, rD = t / D.Tc, r / D.Lc
+                zD = np.array([145.7]) / D.Lc
+                a = plan.drawdown(tD, rD, plan.split_vector(tD), zD, plan.zlay(zD))
+                b = fresh.drawdown(tD, rD, fresh.split_vector(tD), zD, fresh.zlay(zD))
+                assert np.array_equal(a[0], b[0], equal_nan=True) and np.array_equal(a[1], b[1], equal_nan=True), (name, mode, i)
+    dk, ts, P0 = load_deck("neuman74_partpen")
+    plan = engine.Plan(P0)
+    with pytest.raises(UcfError):
+        plan.update(params_from_deck(dk.replace(M=dk.M + 2)))
+    with pytest.raises(UcfError):
+        plan.update(params_from_deck(dk.replace(model=4)))
+
+
 def test_device_entry_orders_by_radius(engine):
     """ucf_drawdown_batch_device on device-resident, unordered points (radii from the overflow regime up): the library
     orders them by radius on the device; same bits as the host entry, which orders them on the host"""

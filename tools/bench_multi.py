@@ -20,6 +20,10 @@ for i in range(npl):
                    Ss=dk.Ss * rng.uniform(0.5, 2.0))
     plans.append(engine.Plan(params_from_deck(d), mode="fast"))
 t_plans = time.time() - t0
+t0 = time.time()
+for i, pl in enumerate(plans):       # the same sets again through ucf_plan_update
+    pl.update(pl.params)
+t_upd = time.time() - t0
 t = 10.0 ** rng.uniform(-1, 4, npts); r = rng.choice([16.0, 30.0, 85.1, 150.0], npts); z = np.array([145.7])
 engine.drawdown_multi(plans, t, r, z)       # warm-up (workspaces)
 best = 1e9
@@ -31,5 +35,5 @@ zD = z / plans[0].derived.Lc
 plans[0].drawdown(tD, rD, plans[0].split_vector(tD), zD, plans[0].zlay(zD))
 t0 = time.time(); plans[0].drawdown(tD, rD, plans[0].split_vector(tD), zD, plans[0].zlay(zD)); one = time.time() - t0
 print(f"{npl} plans x {npts} points: multi {best * 1e3:.1f} ms = {npl * npts / best:.0f} points/s  "
-      f"({best / npl * 1e6:.0f} us per plan); plan creation {t_plans / npl * 1e3:.2f} ms each; "
+      f"({best / npl * 1e6:.0f} us per plan); plan creation {t_plans / npl * 1e3:.2f} ms each, update {t_upd / npl * 1e6:.0f} us each; "
       f"same {npl * npts} points under one plan in one call: {one * 1e3:.1f} ms = {npl * npts / one:.0f} points/s")

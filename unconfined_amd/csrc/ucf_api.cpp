@@ -306,40 +306,46 @@ const char* ucf_status_string(int status)
     }
 }
 
-int ucf_plan_create(const ucf_params* Pin, ucf_plan** out)
+namespace {
+// Everything of a plan that depends on the parameters.  create: also the quadrature tables (which depend only on the
+// numerical settings k, R, ord, nacc, the J0 split) and the device allocation.  !create (ucf_plan_update): the new set
+// must leave those settings and the model alone; only the parameter-dependent table segments (finite-difference
+// exponentials, pumping schedule) are uploaded again.
+int plan_set_params(ucf_plan* pl, const ucf_params& Pin, bool create)
 {
-    if (!Pin || !out) return fail(UCF_ERR_BAD_ARGUMENT, "NULL argument");
-    *out = nullptr;
-    int rc = validate(*Pin);
-    if (rc) return rc;
-    rc = require_device();
-    if (rc) return rc;
-
-    ucf_plan* pl = new (std::nothrow) ucf_plan();
-    if (!pl) return fail(UCF_ERR_NOMEM, "host allocation failed");
-    std::memset(pl, 0, sizeof(*pl));
-    pl->P = *Pin;
-    if (pl->P.tol < DBL_EPSILON) pl->P.tol = DBL_EPSILON;            // driver_io.f90:311-314
+    ucf_params Pn = Pin;
+    if (Pn.tol < DBL_EPSILON) Pn.tol = DBL_EPSILON;                  // driver_io.f90:311-314
+    if (!create) {
+        const ucf_params& O = pl->P;
+        const bool same = O.model == Pn.model && O.MNtype == Pn.MNtype && O.order == Pn.order && O.timeType == Pn.timeType &&
+                          O.MoenchM == Pn.MoenchM && O.M == Pn.M && O.k == Pn.k && O.R == Pn.R && O.nacc == Pn.nacc && O.ord == Pn.ord &&
+                          O.j0s[0] == Pn.j0s[0] && O.j0s[1] == Pn.j0s[1];
+        if (!same)
+            return fail(UCF_ERR_BAD_ARGUMENT, "ucf_plan_update: the model and the numerical settings (M, k, R, nacc, ord, J0 split, "
+                                              "schedule length, FD order, number of Moench terms) must stay as they are; create a new plan");
+    }
+    pl->P = Pn;
     const ucf_params& P = pl->P;
     nondimensionalise(P, pl->D);
     const ucf_derived& D = pl->D;
-    (void)hipGetDevice(&pl->device);
-
     const int N = D.N, R = P.R, ngl = P.ord - 2;
-    pl->h_j0z = (double*)std::malloc(sizeof(double) * D.nj0z);
-    pl->h_ts_x = (double*)std::malloc(sizeof(double) * N);
-    pl->h_ts_w = (double*)std::calloc((size_t)R * N, sizeof(double));
-    pl->h_gl_x = (double*)std::malloc(sizeof(double) * ngl);
-    pl->h_gl_w = (double*)std::malloc(sizeof(double) * ngl);
-    j0_zeros(D.nj0z, pl->h_j0z);
     ucf_dev_params& dp = pl->dev;
-    for (int j = 1; j <= R; j++) {                                    // driver.f90:86-91
-        const int kv = P.k - R + j;
-        pl->Nv[j - 1] = (1 << kv) - 1;
-        dp.hv[j - 1] = 4.0 / (double)(1 << kv);
-        tanh_sinh_level(kv, pl->h_ts_w + (size_t)(j - 1) * N, (j == R) ? pl->h_ts_x : nullptr);
+    if (create) {
+        (void)hipGetDevice(&pl->device);
+        pl->h_j0z = (double*)std::malloc(sizeof(double) * D.nj0z);
+        pl->h_ts_x = (double*)std::malloc(sizeof(double) * N);
+        pl->h_ts_w = (double*)std::calloc((size_t)R * N, sizeof(double));
+        pl->h_gl_x = (double*)std::malloc(sizeof(double) * ngl);
+        pl->h_gl_w = (double*)std::malloc(sizeof(double) * ngl);
+        j0_zeros(D.nj0z, pl->h_j0z);
+        for (int j = 1; j <= R; j++) {                                    // driver.f90:86-91
+            const int kv = P.k - R + j;
+            pl->Nv[j - 1] = (1 << kv) - 1;
+            dp.hv[j - 1] = 4.0 / (double)(1 << kv);
+            tanh_sinh_level(kv, pl->h_ts_w + (size_t)(j - 1) * N, (j == R) ? pl->h_ts_x : nullptr);
+        }
+        gauss_lobatto(P.ord, pl->h_gl_x, pl->h_gl_w);
     }
-    gauss_lobatto(P.ord, pl->h_gl_x, pl->h_gl_w);
 
     // FD table exp(-beta1*(j-1)*h)  (laplace_hankel_solutions.f90:494)
     std::vector<double> fd_e;
@@ -383,26 +389,30 @@ int ucf_plan_create(const ucf_params* Pin, ucf_plan** out)
         sched[2 * n] = P.timeParExt[n];
         sched[2 * n + 1] = sum;
     }
-    // one device allocation for all tables
-    const size_t n_tab = (size_t)N + (size_t)R * N + 2 * (size_t)ngl + D.nj0z + fd_e.size() + sched.size();
-    std::vector<double> host(n_tab);
-    size_t o = 0;
-    const size_t o_tsx = o; std::memcpy(&host[o], pl->h_ts_x, sizeof(double) * N); o += N;
-    const size_t o_tsw = o; std::memcpy(&host[o], pl->h_ts_w, sizeof(double) * (size_t)R * N); o += (size_t)R * N;
-    const size_t o_glx = o; std::memcpy(&host[o], pl->h_gl_x, sizeof(double) * ngl); o += ngl;
-    const size_t o_glw = o; std::memcpy(&host[o], pl->h_gl_w, sizeof(double) * ngl); o += ngl;
-    const size_t o_j0z = o; std::memcpy(&host[o], pl->h_j0z, sizeof(double) * D.nj0z); o += D.nj0z;
-    const size_t o_fde = o; if (!fd_e.empty()) std::memcpy(&host[o], fd_e.data(), sizeof(double) * fd_e.size());
-    o += fd_e.size();
-    const size_t o_sched = o; if (!sched.empty()) std::memcpy(&host[o], sched.data(), sizeof(double) * sched.size());
-    pl->tables_bytes = n_tab * sizeof(double);
-    if (hipMalloc((void**)&pl->d_tables, pl->tables_bytes) != hipSuccess) {
-        ucf_plan_destroy(pl);
-        return fail(UCF_ERR_NOMEM, "hipMalloc of %zu table bytes failed", pl->tables_bytes);
-    }
-    if (hipMemcpy(pl->d_tables, host.data(), pl->tables_bytes, hipMemcpyHostToDevice) != hipSuccess) {
-        ucf_plan_destroy(pl);
-        return fail(UCF_ERR_HIP, "table upload failed");
+    if (create) {
+        // one device allocation for all tables
+        const size_t n_tab = (size_t)N + (size_t)R * N + 2 * (size_t)ngl + D.nj0z + fd_e.size() + sched.size();
+        std::vector<double> host(n_tab);
+        size_t o = 0;
+        pl->o_tsx = o; std::memcpy(&host[o], pl->h_ts_x, sizeof(double) * N); o += N;
+        pl->o_tsw = o; std::memcpy(&host[o], pl->h_ts_w, sizeof(double) * (size_t)R * N); o += (size_t)R * N;
+        pl->o_glx = o; std::memcpy(&host[o], pl->h_gl_x, sizeof(double) * ngl); o += ngl;
+        pl->o_glw = o; std::memcpy(&host[o], pl->h_gl_w, sizeof(double) * ngl); o += ngl;
+        pl->o_j0z = o; std::memcpy(&host[o], pl->h_j0z, sizeof(double) * D.nj0z); o += D.nj0z;
+        pl->o_fde = o; if (!fd_e.empty()) std::memcpy(&host[o], fd_e.data(), sizeof(double) * fd_e.size());
+        o += fd_e.size();
+        pl->o_sched = o; if (!sched.empty()) std::memcpy(&host[o], sched.data(), sizeof(double) * sched.size());
+        pl->tables_bytes = n_tab * sizeof(double);
+        if (hipMalloc((void**)&pl->d_tables, pl->tables_bytes) != hipSuccess)
+            return fail(UCF_ERR_NOMEM, "hipMalloc of %zu table bytes failed", pl->tables_bytes);
+        if (hipMemcpy(pl->d_tables, host.data(), pl->tables_bytes, hipMemcpyHostToDevice) != hipSuccess)
+            return fail(UCF_ERR_HIP, "table upload failed");
+    } else if (!fd_e.empty() || !sched.empty()) {
+        (void)hipDeviceSynchronize();                                  // launches of the old parameter set may still read them
+        if (!fd_e.empty() && hipMemcpy(pl->d_tables + pl->o_fde, fd_e.data(), sizeof(double) * fd_e.size(), hipMemcpyHostToDevice) != hipSuccess)
+            return fail(UCF_ERR_HIP, "table upload failed");
+        if (!sched.empty() && hipMemcpy(pl->d_tables + pl->o_sched, sched.data(), sizeof(double) * sched.size(), hipMemcpyHostToDevice) != hipSuccess)
+            return fail(UCF_ERR_HIP, "table upload failed");
     }
 
     dp.model = P.model; dp.MNtype = P.MNtype; dp.order = P.order; dp.timeType = P.timeType; dp.MoenchM = P.MoenchM;
@@ -423,16 +433,41 @@ int ucf_plan_create(const ucf_params* Pin, ucf_plan** out)
     // and none of the products of two of them that the reference forms may overflow.  Refined per call in
     // fill_call_params (the products depend on the depths).
     dp.fast_eta_max = (dp.fold_dD && dp.fold_lD1) ? 700.0 : 350.0;
-    dp.ts_x = pl->d_tables + o_tsx;
-    dp.ts_w = pl->d_tables + o_tsw;
-    dp.gl_x = pl->d_tables + o_glx;
-    dp.gl_w = pl->d_tables + o_glw;
-    dp.j0z = pl->d_tables + o_j0z;
-    dp.fd_e = pl->d_tables + o_fde;
-    dp.sched = pl->d_tables + o_sched;
+    dp.ts_x = pl->d_tables + pl->o_tsx;
+    dp.ts_w = pl->d_tables + pl->o_tsw;
+    dp.gl_x = pl->d_tables + pl->o_glx;
+    dp.gl_w = pl->d_tables + pl->o_glw;
+    dp.j0z = pl->d_tables + pl->o_j0z;
+    dp.fd_e = pl->d_tables + pl->o_fde;
+    dp.sched = pl->d_tables + pl->o_sched;
+    return UCF_OK;
+}
+}  // namespace
+
+int ucf_plan_create(const ucf_params* Pin, ucf_plan** out)
+{
+    if (!Pin || !out) return fail(UCF_ERR_BAD_ARGUMENT, "NULL argument");
+    *out = nullptr;
+    int rc = validate(*Pin);
+    if (rc) return rc;
+    rc = require_device();
+    if (rc) return rc;
+    ucf_plan* pl = new (std::nothrow) ucf_plan();
+    if (!pl) return fail(UCF_ERR_NOMEM, "host allocation failed");
+    std::memset(pl, 0, sizeof(*pl));
+    rc = plan_set_params(pl, *Pin, true);
+    if (rc) { ucf_plan_destroy(pl); return rc; }
     pl->mode = 0;
     *out = pl;
     return UCF_OK;
+}
+
+int ucf_plan_update(ucf_plan* pl, const ucf_params* Pin)
+{
+    if (!pl || !Pin) return fail(UCF_ERR_BAD_ARGUMENT, "NULL argument");
+    int rc = validate(*Pin);
+    if (rc) return rc;
+    return plan_set_params(pl, *Pin, false);
 }
 
 void ucf_plan_destroy(ucf_plan* pl)

@@ -56,6 +56,7 @@ struct ucf_plan {
     int device;
     double* d_tables;          // one allocation holding all tables
     size_t tables_bytes;
+    size_t o_tsx, o_tsw, o_glx, o_glw, o_j0z, o_fde, o_sched;     // offsets (doubles) of the tables in it
     // host copies (for the accessor API)
     double* h_j0z;
     double* h_ts_x;

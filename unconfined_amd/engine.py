@@ -113,6 +113,15 @@ class Plan:
         _libmod.check(self._lib.ucf_split_vector(self._h, len(tD), tD, out))
         return out
 
+    def update(self, params) -> "Plan":
+        """new hydraulic / geometric / schedule parameters, same model and numerical settings (ucf_plan_update)"""
+        _libmod.check(self._lib.ucf_plan_update(self._h, C.byref(params)))
+        self.params = params
+        d = UcfDerived()
+        _libmod.check(self._lib.ucf_plan_derived(self._h, C.byref(d)))
+        self.derived = d
+        return self
+
     def pvalues(self, tee: float) -> np.ndarray:
         out = np.zeros((self.derived.np, 2))
         _libmod.check(self._lib.ucf_pvalues(self._h, float(tee), out))

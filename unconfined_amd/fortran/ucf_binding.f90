@@ -38,7 +38,7 @@ module ucf_binding
           & wynn_early_exit, wynn_all_zero
   end type ucf_stats
 
-  public :: ucf_version, ucf_last_error, ucf_plan_create, ucf_plan_destroy, ucf_plan_derived, &
+  public :: ucf_version, ucf_last_error, ucf_plan_create, ucf_plan_destroy, ucf_plan_update, ucf_plan_derived, &
        & ucf_plan_set_mode, ucf_logspace, ucf_linspace, ucf_zlay, ucf_split_vector, &
        & ucf_drawdown_grid, ucf_drawdown_batch, ucf_screen_average, ucf_error_message
 
@@ -64,6 +64,13 @@ module ucf_binding
        import :: c_ptr
        type(c_ptr), value :: plan
      end subroutine ucf_plan_destroy
+
+     function ucf_plan_update(plan, P) bind(C, name='ucf_plan_update') result(rc)
+       import :: c_int, c_ptr, ucf_params
+       type(c_ptr), value :: plan
+       type(ucf_params), intent(in) :: P
+       integer(c_int) :: rc
+     end function ucf_plan_update
 
      function ucf_plan_derived(plan, D) bind(C, name='ucf_plan_derived') result(rc)
        import :: c_int, c_ptr, ucf_derived

@@ -22,7 +22,7 @@ _ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
 
 EXPORTS = [
     "ucf_version", "ucf_last_error", "ucf_status_string",
-    "ucf_plan_create", "ucf_plan_destroy", "ucf_plan_derived", "ucf_plan_j0z", "ucf_plan_tanh_sinh",
+    "ucf_plan_create", "ucf_plan_destroy", "ucf_plan_update", "ucf_plan_derived", "ucf_plan_j0z", "ucf_plan_tanh_sinh",
     "ucf_plan_gauss_lobatto", "ucf_plan_set_mode", "ucf_plan_set_timing", "ucf_plan_kernel_ms",
     "ucf_logspace", "ucf_linspace", "ucf_zlay", "ucf_split_vector",
     "ucf_drawdown_batch", "ucf_drawdown_batch_device", "ucf_drawdown_grid", "ucf_drawdown_grid_device",
@@ -68,6 +68,7 @@ def load() -> C.CDLL:
     lib.ucf_status_string.argtypes = [C.c_int]
     lib.ucf_plan_create.argtypes = [C.POINTER(UcfParams), C.POINTER(vp)]
     lib.ucf_plan_destroy.argtypes = [vp]
+    lib.ucf_plan_update.argtypes = [vp, C.POINTER(UcfParams)]
     lib.ucf_plan_destroy.restype = None
     lib.ucf_plan_derived.argtypes = [vp, C.POINTER(UcfDerived)]
     lib.ucf_plan_j0z.argtypes = [vp, C.c_int, _dp]
