@@ -4,35 +4,46 @@ configs[1], SURVEY.md section 8d "C2"): model 5 with beta = 0, fully penetrating
 M = 26 (53 Laplace samples), tanh-sinh k = 6 / R = 4, 10 J0 intervals x 48 Gauss-Lobatto
 nodes => 543 abscissae, 28 779 Laplace-Hankel samples per point, fp64 throughout.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--mode faithful|fast]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling strong|weak] [--workload c2|c2pp|c3|c4|c5]
+                  [--mode fast|faithful]
 
-One "step" = one pass of the hot path over the whole synthetic sweep that is resident
-in HBM (times tD[1024] with their split index, radii rD[256] in; h and dh per point out).  With N > 1 the
-driver launches this file under torch.distributed.run; the flattened (t,r) index is
-block-partitioned over ranks (weak scaling: every rank owns a full 1024x256 block of
-a 1024 x 256N sweep), no data-path collective, and each step ends with the RCCL
-all-gather of the (h, dh) results that the reference's single output file implies.
+One "step" = one pass of the hot path over the whole synthetic sweep that is resident in HBM
+(times tD[nt] with their split index, radii rD[nr] in; h and dh per point out).
+
+N > 1: one process per GPU over RCCL.  Under torch.distributed.run (RANK / WORLD_SIZE in the
+environment) this file is a rank; started plainly with --gpus N it launches its N ranks itself
+(fresh child processes, before anything here touches a GPU) and fails if RCCL does not see N ranks.
+  --scaling strong (default)  the FIXED sweep of the workload (C2 1024x256, C4 4096x1024, ...) is cut into N contiguous
+                              blocks of time rows (ucf_shard_rows: the reference's i loop, driver.f90:100); every
+                              rank computes its rows in place in the full-size result arrays and one in-place
+                              all-gather per array completes them on every rank (the reference's single output).
+  --scaling weak              every rank owns a full nt x nr sweep of its own block of radii (nt x nr*N in all).
+No data-path collective in either; the gather is inside the timed step.  The other mode is measured after the
+timed region and reported under "other_scaling".
 
 The JSON line carries
-  roofline      : bound = fp64 VALU (this path is neither HBM- nor MFMA-bound, SURVEY 8d);
-                  achieved = algorithmic flop per launch / average kernel duration
-                  (HIP events on the launch stream); peak = 78.6 TFLOP/s (fp64 vector,
-                  = 1/2 of the 157.3 TF fp32 vector figure of MI355X_MICROARCH.md); the
-                  measured fp64-FMA rate of this device and the HBM view are added.
-  cpu_baseline  : the reference binary itself (oracle/_ref/O2/unconfined, flang -O2,
-                  OpenMP on all host cores) when it was shipped with the repo, else the
-                  C oracle; timed on a bounded sample of the same workload, rank 0, N=1.
+  roofline      : bound = fp64 VALU (this path is neither HBM- nor MFMA-bound).  `achieved` = fp64 flop the
+                  dominant kernel EXECUTES per launch / its average duration over the timed steps (HIP events recorded by
+                  the library on the launch stream around every kernel); the executed-flop count comes from the
+                  rocprofv3 --pmc profile under profiles/ that carries this library's build id (tools/gpu_final.sh
+                  regenerates it in the same pass as the kernel trace) -- a profile of another build is refused and
+                  the field is null.  `peak` = 78.6 TFLOP/s (fp64 vector = 1/2 of the 157.3 TF fp32 vector figure of
+                  MI355X_MICROARCH.md).  `kernels` = the same for every kernel of the step.  The SURVEY 8(d)
+                  convention figure (flop of the REFERENCE formulation / kernel time) is kept apart as
+                  `time_to_solution_vs_reference_formulation`: it is not a utilisation.
+  cpu_baseline  : the reference binary itself (oracle/_ref/O2/unconfined, flang -O2, OpenMP) when it was shipped with
+                  the repo, else the C oracle; timed on a bounded sample of the same workload, rank 0, N = 1.
+  accuracy_vs_cpu_ref : the second half of the metric, both flavours, on that sample (outside the timed region).
 """
 import argparse
 import json
 import os
 import shutil
+import socket
 import subprocess
 import sys
 import tempfile
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -42,6 +53,7 @@ FLOP_PER_SAMPLE = 1420.0
 FLOP_TAIL_PER_POINT = 0.1e6
 PEAK_FP64_VALU_TFLOPS = 78.6
 PEAK_HBM_GBS = 8000.0
+PROFILE = os.path.join(ROOT, "profiles", "pmc_r02.json")
 
 
 def c2_deck():
@@ -73,6 +85,7 @@ def workload_deck(name):
 
 def cpu_baseline(dk, ncores):
     """reference CPU throughput on a bounded sample (8 radii x 1024 times of the C2 sweep, ~10-15 s)"""
+    import numpy as np
     from unconfined_amd.deck import TimeSpec
     ref = os.path.join(ROOT, "oracle", "_ref", "O2", "unconfined")
     radii = [16.0, 29.6, 54.9, 84.8, 160.0, 480.0, 960.0, 1600.0]      # spans the sweep's rD = 0.1 .. 10
@@ -121,225 +134,378 @@ def cpu_baseline(dk, ncores):
             "_radii": radii, "_rows": np.stack([np.tile(t, len(radii)), ho[:, 0] * D.Hc, dho[:, 0] * D.Hc], axis=1)}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--mode", default=os.environ.get("UCF_BENCH_MODE", "fast"), choices=["faithful", "fast"])
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"])
     ap.add_argument("--workload", default="c2", choices=["c2", "c2pp", "c3", "c4", "c5"])
     ap.add_argument("--nt", type=int, default=0)
     ap.add_argument("--nr", type=int, default=0)
     ap.add_argument("--layout", default="auto", choices=["auto", "sample"])
     ap.add_argument("--no-cpu", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--no-other-scaling", action="store_true")
+    return ap.parse_args(argv)
 
+
+def self_launch(args):
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks as fresh child processes (this
+    process has not touched a GPU and never will) and pass on rank 0's line; non-zero exit if any rank fails"""
+    n = args.gpus
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), UCF_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    deadline = time.time() + float(os.environ.get("UCF_BENCH_LAUNCH_TIMEOUT", "1500"))
+    alive = set(range(n))
+    while alive:
+        for r in sorted(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                print(f"[bench] rank {r} exited with code {code}; stopping the others", file=sys.stderr)
+                for q in alive:
+                    procs[q].terminate()
+        if time.time() > deadline:
+            print("[bench] ranks did not finish in time; stopping them", file=sys.stderr)
+            for q in alive:
+                procs[q].kill()
+            rc = rc or 124
+            break
+        time.sleep(0.05)
+    for p in procs:
+        try:
+            p.wait(timeout=30)
+        except Exception:
+            p.kill()
+    return rc
+
+
+def load_profile(build_id, workload, mode):
+    """per-kernel counters of this workload from profiles/pmc_r02.json -- only if they were taken on THIS build"""
+    try:
+        prof = json.load(open(PROFILE))
+    except Exception as exc:
+        return None, f"no profile ({exc.__class__.__name__})"
+    ent = prof.get("workloads", {}).get(workload, {}).get(mode)
+    if not ent:
+        return None, f"profile has no entry for workload {workload} / {mode}"
+    if ent.get("build_id") != build_id:
+        return None, f"profile was taken on build {ent.get('build_id')}, this library is build {build_id}: refused"
+    return ent, f"profiles/pmc_r02.json (rocprofv3 --pmc, build {build_id}, {ent.get('points_per_launch')} points per launch)"
+
+
+def worker(args):
+    import numpy as np
     import torch
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the drawdown path has no CPU fallback")
+    if args.gpus != world:
+        if rank == 0:
+            print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a line for the wrong GPU count", file=sys.stderr)
+        return 5
     # UCF_BENCH_BACKEND=gloo + UCF_BENCH_ONE_DEVICE=1: rehearsal of the N > 1 logic on a one-GPU box (all
     # ranks on cuda:0, gather staged through the host); the graded runs use RCCL, one rank per GPU
     backend = os.environ.get("UCF_BENCH_BACKEND", "nccl")
-    if os.environ.get("UCF_BENCH_ONE_DEVICE") == "1":
+    one_device = os.environ.get("UCF_BENCH_ONE_DEVICE") == "1"
+    ndev = torch.cuda.device_count()
+    if ndev < 1 or (not one_device and local_rank >= ndev):
+        print(f"[bench] rank {rank}: needs GPU {local_rank}, {ndev} visible (the drawdown path has no CPU fallback)", file=sys.stderr)
+        return 3
+    if one_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
+        # how many ranks does the collective library really see?
+        cnt = torch.ones(1, dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(cnt)
+        n_ranks = int(cnt.item())
+        if n_ranks != args.gpus:
+            if rank == 0:
+                print(f"[bench] {backend} reports {n_ranks} ranks, --gpus asked for {args.gpus}", file=sys.stderr)
+            return 4
+    else:
+        n_ranks = 1
 
-    from unconfined_amd import engine
+    from unconfined_amd import engine, sharding
     from unconfined_amd.abi import params_from_deck
 
     dk, nt_def, nr_def, wl_name = workload_deck(args.workload)
-    args.nt = args.nt or nt_def
-    args.nr = args.nr or nr_def
+    nt = args.nt or nt_def
+    nr = args.nr or nr_def
     P = params_from_deck(dk)
     plan = engine.Plan(P, mode=args.mode, layout=args.layout)
     D = plan.derived
-
-    # ---- the sweep: 1024 log-spaced times x (256 * world) log-spaced radii, rank owns a block of 256 radii
-    nt, nr = args.nt, args.nr
     t = engine.logspace(-1, 8, nt)
     tD = t / D.Tc
     sv_t = plan.split_vector(tD)
-    rD_all = 10.0 ** engine.linspace(-1.0, 1.0, nr * world)
-    rD_mine = rD_all[rank * nr:(rank + 1) * nr]
-    npts = nt * nr
     zD = engine.linspace(dk.zBot, dk.zTop, 1 if dk.piezometer else dk.zOrd) / D.Lc
     zl = plan.zlay(zD)
     nz = len(zD)
-
-    dev = torch.device("cuda", local_rank)
-    d_tD = torch.from_numpy(np.ascontiguousarray(tD)).to(dev)                 # [nt]
-    d_rD = torch.from_numpy(np.ascontiguousarray(rD_mine)).to(dev)            # [nr]
-    d_sv = torch.from_numpy(sv_t.astype(np.int32)).to(dev)                    # [nt]
-    d_out = torch.zeros(2, npts * nz, dtype=torch.float64, device=dev)       # [h; dh]
-    d_all = torch.zeros(world * 2, npts * nz, dtype=torch.float64, device=dev) if world > 1 else None
     stream = torch.cuda.current_stream()
+    d_tD = torch.from_numpy(np.ascontiguousarray(tD)).to(dev)                 # [nt]
+    d_sv = torch.from_numpy(sv_t.astype(np.int32)).to(dev)                    # [nt]
 
-    def gather():
-        if backend == "nccl":
-            dist.all_gather_into_tensor(d_all, d_out)
-        else:                                   # rehearsal path only
-            host_all = torch.empty(d_all.shape, dtype=d_all.dtype)
-            dist.all_gather_into_tensor(host_all, d_out.cpu())
-            d_all.copy_(host_all)
+    def to_host_gather(full_dev, gather_fn):           # rehearsal path only (gloo): stage through the host
+        host = full_dev.cpu()
+        gather_fn(host)
+        full_dev.copy_(host)
 
-    def step():
-        plan.drawdown_grid_device(nt, d_tD.data_ptr(), d_sv.data_ptr(), nr, d_rD.data_ptr(), zD, zl,
+    # ---- strong scaling: the fixed nt x nr sweep, rows block-partitioned (ucf_shard_rows), results in place
+    row = nr * nz
+    prow = sharding.padded_rows(nt, world)
+    lo, hi = sharding.shard_rows(nt, world, rank)
+    rD_fixed = 10.0 ** engine.linspace(-1.0, 1.0, nr)
+    d_rD_fixed = torch.from_numpy(np.ascontiguousarray(rD_fixed)).to(dev)
+    d_full = torch.zeros(2, prow * row, dtype=torch.float64, device=dev)      # [h; dh] x [prow][nr][nz]
+
+    def step_strong(gather=True):
+        plan.drawdown_grid_shard_device(rank, world, nt, d_tD.data_ptr(), d_sv.data_ptr(), nr, d_rD_fixed.data_ptr(), zD, zl,
+                                        d_full[0].data_ptr(), d_full[1].data_ptr(), stream=stream.cuda_stream)
+        if world > 1 and gather:
+            for a in (0, 1):
+                if backend == "nccl":
+                    sharding.allgather_rows_(d_full[a], nt, row, world, rank)
+                else:
+                    to_host_gather(d_full[a], lambda hst: sharding.allgather_rows_(hst, nt, row, world, rank))
+
+    # ---- weak scaling: nt x (nr * world) sweep, every rank a block of nr radii
+    rD_all = 10.0 ** engine.linspace(-1.0, 1.0, nr * world)
+    d_rD_mine = torch.from_numpy(np.ascontiguousarray(rD_all[rank * nr:(rank + 1) * nr])).to(dev)
+    d_out = d_all = None
+
+    def alloc_weak():
+        nonlocal d_out, d_all
+        if d_out is None:
+            d_out = torch.zeros(2, nt * row, dtype=torch.float64, device=dev)
+            d_all = torch.zeros(world * 2, nt * row, dtype=torch.float64, device=dev) if world > 1 else None
+
+    def step_weak(gather=True):
+        plan.drawdown_grid_device(nt, d_tD.data_ptr(), d_sv.data_ptr(), nr, d_rD_mine.data_ptr(), zD, zl,
                                   d_out[0].data_ptr(), d_out[1].data_ptr(), stream=stream.cuda_stream)
-        if world > 1:
-            gather()
+        if world > 1 and gather:
+            if backend == "nccl":
+                dist.all_gather_into_tensor(d_all, d_out)
+            else:
+                host_all = torch.empty(d_all.shape, dtype=d_all.dtype)
+                dist.all_gather_into_tensor(host_all, d_out.cpu())
+                d_all.copy_(host_all)
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    # dominant-kernel duration: HIP events recorded by the library on the launch stream right around that
-    # kernel (ucf_plan_set_timing), read back after each of the same K timed steps; the events around the
-    # whole call (all kernels of a step) are kept as `step_kernels_ms`
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    plan.set_timing(True)
-    dom_ms, dom_name = [], ""
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        if k > 0:
+    def timed(step_fn, steps, warmup, with_kernel_times):
+        """the contract's timed region: W warm-up steps, barrier + synchronize, K steps, synchronize + barrier, max over ranks"""
+        for _ in range(warmup):
+            step_fn()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        plan.set_timing(with_kernel_times)
+        per_kernel = {}
+        order = []
+
+        def collect():
             try:
-                ms_k, dom_name = plan.kernel_ms()       # waits for step k-1's kernel only
-                dom_ms.append(ms_k)
+                for name, ms in plan.kernel_times():        # waits for the previous step's kernels only
+                    if name not in per_kernel:
+                        per_kernel[name] = []
+                        order.append(name)
+                    per_kernel[name].append(ms)
             except Exception:
                 pass
-        ev[k][0].record(stream)
-        plan.drawdown_grid_device(nt, d_tD.data_ptr(), d_sv.data_ptr(), nr, d_rD.data_ptr(), zD, zl,
-                                  d_out[0].data_ptr(), d_out[1].data_ptr(), stream=stream.cuda_stream)
-        ev[k][1].record(stream)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            if k > 0 and with_kernel_times:
+                collect()
+            step_fn()
+        torch.cuda.synchronize()
         if world > 1:
-            gather()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        if with_kernel_times:
+            collect()
+        plan.set_timing(False)
+        if world > 1:
+            tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        return elapsed, [(n, float(np.mean(per_kernel[n]))) for n in order]
+
+    if args.scaling == "weak":
+        alloc_weak()
+    main_step = step_strong if args.scaling == "strong" else step_weak
+    elapsed, kernels = timed(main_step, args.steps, args.warmup, True)
+    pts_main = (nt * nr if args.scaling == "strong" else nt * nr * world)
+    pts_launch = ((hi - lo) * nr if args.scaling == "strong" else nt * nr)       # points of one rank's launch
+
+    # sanity: finite results, and every rank holds the same gathered sweep
+    if args.scaling == "strong":
+        hh = d_full[0][: nt * row]
+        ok = bool(torch.isfinite(hh).all().item())
+        if world > 1:
+            chk = torch.stack([hh.sum(), d_full[1][: nt * row].sum()])
+            if backend != "nccl":
+                chk = chk.cpu()
+            lo_, hi_ = chk.clone(), chk.clone()
+            dist.all_reduce(lo_, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi_, op=dist.ReduceOp.MAX)
+            ok = ok and bool(torch.equal(lo_, hi_))
+    else:
+        ok = bool(torch.isfinite(d_out[0]).all().item())
+        if world > 1:
+            ok = ok and bool(torch.equal(d_all[2 * rank:2 * rank + 2], d_out))
+
+    other = None
+    if world > 1 and not args.no_other_scaling:
+        if args.scaling == "strong":
+            alloc_weak()
+            e2, _ = timed(step_weak, args.steps, 1, False)
+            other = {"scaling": "weak", "value": nt * nr * world * args.steps / e2, "ms_per_step": e2 / args.steps * 1e3,
+                     "points_per_step": nt * nr * world}
+        else:
+            e2, _ = timed(step_strong, args.steps, 1, False)
+            other = {"scaling": "strong", "value": nt * nr * args.steps / e2, "ms_per_step": e2 / args.steps * 1e3,
+                     "points_per_step": nt * nr}
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return 0
+
+    value = pts_main * args.steps / elapsed
+    samples_per_pt = D.nabs * D.np * nz
+    per_sample = FLOP_PER_SAMPLE if dk.model in (3, 5) else (30.0 if dk.model == 0 else FLOP_PER_SAMPLE)
+    if dk.model == 6 and dk.MNtype == 2:
+        per_sample += dk.order * 68.0            # SURVEY 8d: n*(1 cdiv + 3 cmul + 2 cadd)*2 passes
+    flop_per_pt = per_sample * D.nabs * D.np + 0.35 * per_sample * D.nabs * D.np * (nz - 1) + FLOP_TAIL_PER_POINT * nz
     try:
-        ms_k, dom_name = plan.kernel_ms()
-        dom_ms.append(ms_k)
+        fma_peak = engine.fp64_fma_peak()
     except Exception:
-        pass
-    step_kernels_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-    kern_ms = float(np.mean(dom_ms)) if dom_ms else step_kernels_ms
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-
-    # sanity: results are finite and the gathered copy equals the local one
-    h_host = d_out[0].cpu().numpy()
-    ok = bool(np.isfinite(h_host).all())
-    if world > 1:
-        ok = ok and bool(torch.equal(d_all[2 * rank:2 * rank + 2], d_out))
-
-    if rank == 0:
-        total_pts = npts * world * args.steps
-        value = total_pts / elapsed
-        samples_per_pt = D.nabs * D.np * nz
-        per_sample = FLOP_PER_SAMPLE if dk.model in (3, 5) else (30.0 if dk.model == 0 else FLOP_PER_SAMPLE)
-        if dk.model == 6 and dk.MNtype == 2:
-            per_sample += dk.order * 68.0            # n*(1 cdiv + 3 cmul + 2 cadd)*2 passes
-        flop_per_pt = per_sample * D.nabs * D.np + 0.35 * per_sample * D.nabs * D.np * (nz - 1) + FLOP_TAIL_PER_POINT * nz
-        achieved_tf = flop_per_pt * npts / (kern_ms * 1e-3) * 1e-12
+        fma_peak = None
+    build_id = engine.build_id()
+    prof, prof_src = load_profile(build_id, args.workload, args.mode)
+    dom = max(kernels, key=lambda kv: kv[1]) if kernels else ("all kernels of a step", elapsed / args.steps * 1e3)
+    rows = []
+    for name, ms in kernels:
+        r = {"name": name, "ms": ms}
+        pk = (prof or {}).get("kernels", {}).get(name)
+        if pk:
+            scale = pts_launch / float(prof["points_per_launch"])          # counters are proportional to the points of a launch
+            if pk.get("fp64_flop_per_launch") is not None:
+                fl = pk["fp64_flop_per_launch"] * scale
+                r.update({"fp64_flop_per_launch": fl, "executed_TFLOPs": fl / (ms * 1e-3) * 1e-12,
+                          "frac": fl / (ms * 1e-3) * 1e-12 / PEAK_FP64_VALU_TFLOPS})
+            if pk.get("hbm_bytes_per_launch") is not None:
+                by = pk["hbm_bytes_per_launch"] * scale
+                r.update({"hbm_bytes_per_launch": by, "hbm_GBs": by / (ms * 1e-3) * 1e-9, "hbm_frac": by / (ms * 1e-3) * 1e-9 / PEAK_HBM_GBS})
+            for k in ("valu_busy", "valu_per_wave_abscissa", "salu_per_wave_abscissa", "fp64_arith_per_wave_abscissa"):
+                if pk.get(k) is not None:
+                    r[k] = pk[k]
+        rows.append(r)
+    drow = next((r for r in rows if r["name"] == dom[0]), {})
+    alg_bytes = (20 + 16 * nz) * pts_launch
+    conv_tf = flop_per_pt * pts_launch / (dom[1] * 1e-3) * 1e-12
+    line = {
+        "metric": "(t,r) drawdown points/sec, Neuman-1974 1024x256 sweep; max |rel err| vs CPU ref",
+        "value": value, "unit": "points/s", "n_gpus": n_ranks, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{wl_name}, {nt} log-spaced times x {nr if args.scaling == 'strong' else nr * world} log-spaced radii"
+                               f"{'' if args.scaling == 'strong' else f' ({nr} per GPU)'}, M={dk.M}, k={dk.k}/R={dk.R}, nacc={dk.nacc}, "
+                               f"ord={dk.ord} ({D.nabs} abscissae, {samples_per_pt} samples/point)",
+                   "points_per_step": pts_main, "points_per_gpu": pts_launch, "mode": args.mode, "layout": args.layout,
+                   "partition": ("contiguous blocks of time rows (ucf_shard_rows), in-place all-gather of h and dh" if args.scaling == "strong"
+                                 else "one block of radii per rank, all-gather of [h; dh]") + f", one rank per GPU, backend {backend if world > 1 else 'none'}",
+                   "launcher": "self (bench.py spawned its ranks)" if os.environ.get("UCF_BENCH_SELF_LAUNCHED") else ("torch.distributed.run" if world > 1 else "single process"),
+                   "build_id": build_id, "results_finite_and_gather_consistent": ok},
+        "roofline": {"bound": "fp64_valu", "achieved": drow.get("executed_TFLOPs"), "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s",
+                     "frac": drow.get("frac"), "traffic": drow.get("hbm_bytes_per_launch"),
+                     "kernel": dom[0], "kernel_ms": dom[1], "step_kernels_ms": float(sum(ms for _, ms in kernels)) if kernels else None,
+                     "definition": "achieved = fp64 flop EXECUTED by the dominant kernel per launch (64 lanes x (2 FMA + ADD + MUL + TRANS) wave "
+                                   "instructions, rocprofv3 --pmc) / its average launch duration over the timed steps (HIP events on the launch stream)",
+                     "executed_flop_source": prof_src,
+                     "kernels": rows,
+                     "valu_busy": drow.get("valu_busy"),
+                     "peak_measured_fp64_fma": fma_peak,
+                     "frac_of_measured_fma": (drow["executed_TFLOPs"] / fma_peak) if (fma_peak and drow.get("executed_TFLOPs")) else None,
+                     "time_to_solution_vs_reference_formulation": {
+                         "flop_per_point": flop_per_pt, "TFLOPs_equivalent": conv_tf, "x_fp64_peak": conv_tf / PEAK_FP64_VALU_TFLOPS,
+                         "convention": "SURVEY.md 8(d): 1.42 kflop per Laplace-Hankel sample as the REFERENCE formulates it (+0.1 Mflop tail per "
+                                       "point) / dominant-kernel time; > 1 x peak means the kernel needs fewer flops than that formulation -- a "
+                                       "time-to-solution figure, not a utilisation"},
+                     "hbm": {"algorithmic_bytes_per_launch": alg_bytes,
+                             "achieved_GBs": alg_bytes / (dom[1] * 1e-3) * 1e-9, "peak_GBs": PEAK_HBM_GBS,
+                             "frac": alg_bytes / (dom[1] * 1e-3) * 1e-9 / PEAK_HBM_GBS}},
+    }
+    if other:
+        line["other_scaling"] = other
+    if world == 1 and not args.no_cpu:
+        # the box shows every hardware thread of the host but a 1-GPU job owns a 16-core share; the
+        # reference's OpenMP regions are 48-63 iterations long, so more threads only add overhead
+        navail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        ncores = int(os.environ.get("UCF_CPU_THREADS", min(16, navail)))
+        cb = cpu_baseline(dk if args.workload == "c2" else c2_deck(), ncores)
+        # the second half of the metric: max |rel err| of the GPU path against the CPU reference on the
+        # sample the CPU leg just computed (same deck, same times; outside the timed region), both flavours
         try:
-            fma_peak = engine.fp64_fma_peak()
-        except Exception:
-            fma_peak = None
-        alg_bytes = (20 + 16 * nz) * npts
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
-        if os.path.exists(tpath):
-            try:
-                # measured on the full 1024 x 256 C2 sweep; traffic is proportional to the points of a launch
-                traffic = json.load(open(tpath)).get(args.mode, {}).get("hbm_bytes_per_launch")
-                if traffic is not None:
-                    traffic = traffic * (npts / 262144.0) if wl_name.startswith("C2:") else None
-            except Exception:
-                traffic = None
-        executed = None
-        ppath = os.path.join(ROOT, "profiles", "pmc_r01.json")
-        if os.path.exists(ppath) and wl_name.startswith("C2:") and args.mode == "fast":
-            try:
-                pm = json.load(open(ppath))["fast"]
-                fl = pm.get("fp64_flop_executed_per_launch")
-                if fl:
-                    fl = fl * (npts / 262144.0)          # counted on the full 1024 x 256 sweep
-                    executed = {"fp64_flop_per_launch": fl, "TFLOPs": fl / (kern_ms * 1e-3) * 1e-12,
-                                "frac_of_peak": fl / (kern_ms * 1e-3) * 1e-12 / PEAK_FP64_VALU_TFLOPS,
-                                "valu_busy": pm.get("valu_busy_per_simd"), "source": "profiles/pmc_r01.json (rocprofv3 --pmc of this workload)"}
-            except Exception:
-                executed = None
-        line = {
-            "metric": "(t,r) drawdown points/sec, Neuman-1974 1024x256 sweep; max |rel err| vs CPU ref",
-            "value": value, "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{wl_name}, {nt} log-spaced times x {nr} "
-                                   f"log-spaced radii per GPU, M={dk.M}, k={dk.k}/R={dk.R}, nacc={dk.nacc}, ord={dk.ord} ({D.nabs} abscissae, "
-                                   f"{samples_per_pt} samples/point)",
-                       "points_per_gpu": npts, "mode": args.mode, "layout": args.layout, "partition": "contiguous (t,r) blocks, one rank per GPU",
-                       "results_finite_and_gather_consistent": ok},
-            "roofline": {"bound": "fp64_valu", "achieved": achieved_tf, "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved_tf / PEAK_FP64_VALU_TFLOPS, "traffic": traffic,
-                         "kernel": dom_name or "all kernels of a step", "kernel_ms": kern_ms,
-                         "step_kernels_ms": step_kernels_ms, "flop_per_point": flop_per_pt,
-                         "convention": "SURVEY.md 8(d): 1.42 kflop per Laplace-Hankel sample as the reference formulates it (+0.1 Mflop tail per point); "
-                                       "frac > 1 = the kernel needs fewer flops than that formulation, see `executed` for the instructions it really issues",
-                         "executed": executed,
-                         "peak_measured_fp64_fma": fma_peak,
-                         "frac_of_measured_fma": (achieved_tf / fma_peak) if fma_peak else None,
-                         "hbm": {"algorithmic_bytes_per_launch": alg_bytes,
-                                 "achieved_GBs": alg_bytes / (kern_ms * 1e-3) * 1e-9, "peak_GBs": PEAK_HBM_GBS,
-                                 "frac": alg_bytes / (kern_ms * 1e-3) * 1e-9 / PEAK_HBM_GBS}},
-        }
-        if world == 1 and not args.no_cpu:
-            # the box shows every hardware thread of the host but a 1-GPU job owns a 16-core share; the
-            # reference's OpenMP regions are 48-63 iterations long, so more threads only add overhead
-            navail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-            ncores = int(os.environ.get("UCF_CPU_THREADS", min(16, navail)))
-            cb = cpu_baseline(dk, ncores)
-            # the second half of the metric: max |rel err| of the GPU path against the CPU reference on the
-            # sample the CPU leg just computed (same deck, same times; outside the timed region)
-            try:
-                rows = cb.pop("_rows")
-                rr = np.array(cb.pop("_radii")) / D.Lc
-                tDs = engine.logspace(-1, 8, 1024) / D.Tc
-                hg, dg = plan.drawdown_grid(tDs, plan.split_vector(tDs), rr, zD, zl)
-                hg = hg[:, :, 0].T.ravel() * D.Hc
-                dg = dg[:, :, 0].T.ravel() * D.Hc
-                eh = np.abs(hg - rows[:, 1]) / np.maximum(np.abs(rows[:, 1]), 1e-3)
-                ed = np.abs(dg - rows[:, 2]) / np.maximum(np.abs(rows[:, 2]), 1e-3)
-                line["accuracy_vs_cpu_ref"] = {
-                    "points": int(len(eh)), "floor": 1e-3,
+            rows_ref = cb.pop("_rows")
+            rr = np.array(cb.pop("_radii"))
+            acc = {"points": int(len(rows_ref)), "floor": 1e-3,
+                   "note": "reference -O2 vs -O3 -march=native builds differ by 1.7e-10 (h) / 4e-8 (dh) on this deck (SURVEY.md H1)"}
+            Pc = params_from_deck(c2_deck())
+            for flavour in ("fast", "faithful"):
+                pl2 = engine.Plan(Pc, mode=flavour)
+                D2 = pl2.derived
+                zD2 = np.array([145.7 / D2.Lc]); zl2 = pl2.zlay(zD2)
+                tDs = engine.logspace(-1, 8, 1024) / D2.Tc
+                hg, dg = pl2.drawdown_grid(tDs, pl2.split_vector(tDs), rr / D2.Lc, zD2, zl2)
+                hg = hg[:, :, 0].T.ravel() * D2.Hc
+                dg = dg[:, :, 0].T.ravel() * D2.Hc
+                eh = np.abs(hg - rows_ref[:, 1]) / np.maximum(np.abs(rows_ref[:, 1]), 1e-3)
+                ed = np.abs(dg - rows_ref[:, 2]) / np.maximum(np.abs(rows_ref[:, 2]), 1e-3)
+                acc[flavour] = {
                     "h_max_rel": float(eh.max()), "h_median_rel": float(np.median(eh)), "h_frac_within_1e-10": float(np.mean(eh <= 1e-10)),
-                    "dh_max_rel": float(ed.max()), "dh_median_rel": float(np.median(ed)), "dh_frac_within_1e-10": float(np.mean(ed <= 1e-10)),
-                    "note": "reference -O2 vs -O3 -march=native builds differ by 1.7e-10 (h) / 4e-8 (dh) on this deck (SURVEY.md H1)"}
-            except Exception as exc:
-                line["accuracy_vs_cpu_ref"] = {"error": str(exc)}
-            cb.pop("_rows", None); cb.pop("_radii", None)
-            line["cpu_baseline"] = cb
-            line["gpu_over_cpu"] = value / cb["value"]
-        print(json.dumps(line))
+                    "dh_max_rel": float(ed.max()), "dh_median_rel": float(np.median(ed)), "dh_frac_within_1e-10": float(np.mean(ed <= 1e-10))}
+                pl2.close()
+            line["accuracy_vs_cpu_ref"] = acc
+        except Exception as exc:
+            line["accuracy_vs_cpu_ref"] = {"error": str(exc)}
+        cb.pop("_rows", None); cb.pop("_radii", None)
+        line["cpu_baseline"] = cb
+        line["gpu_over_cpu"] = value / cb["value"] if args.workload == "c2" else None
+    print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    return 0
+
+
+def main():
+    args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return self_launch(args)
+    return worker(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

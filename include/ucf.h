@@ -19,8 +19,17 @@
  *   - "in-band" numerical rules of the reference (NaN->0 scrub, Wynn-epsilon
  *     truncation/sentinel, epsilon-table early exit, FD underflow guard) are
  *     part of the numerical contract and are reproduced on the device;
- *   - a plan is immutable after creation; batch calls on one plan are
- *     re-entrant as long as each call uses its own stream/output buffers.
+ *   - threading / streams (the reference calls its procedures from OpenMP threads with shared read-only
+ *     parameter objects, driver.f90:129-230): any number of host threads may call the drawdown entry points on ONE
+ *     plan at the same time.  Everything a call writes lives in a workspace that the plan keeps PER HIP STREAM:
+ *     calls on different streams share nothing and run concurrently; calls that name the same stream (the host
+ *     entry points all use the default stream) are enqueued one after the other under the workspace's lock and
+ *     execute in stream order.  The *_device entry points never synchronise; they allocate only when a workspace
+ *     must grow (outgrown buffers are kept until the stream has drained, never freed under a running kernel), and not
+ *     at all after ucf_plan_reserve -- which is what capturing them into a hipGraph needs.
+ *     What may NOT overlap with calls in flight on the same plan: ucf_plan_update, ucf_plan_set_mode,
+ *     ucf_plan_set_timing, ucf_plan_destroy (the caller orders those; ucf_plan_update waits for the plan's own
+ *     streams before it rewrites a device table).
  *   - there is NO CPU fallback: every compute entry point fails with
  *     UCF_ERR_NO_DEVICE if no gfx950-capable HIP device is usable.
  */
@@ -142,10 +151,23 @@ int ucf_plan_gauss_lobatto(const ucf_plan* plan, int n, double* x, double* w);
  *                 1 = fast (same algorithm, FMA contraction + shared subexpressions). */
 int ucf_plan_set_mode(ucf_plan* plan, int mode);
 
-/* measurement: when enabled, the dominant kernel of every following grid call is bracketed by HIP
- * events on its stream; ucf_plan_kernel_ms waits for the last bracket and returns its duration and name. */
+/* measurement: when enabled, every kernel of a following single-chunk grid call (lane = time layout) is bracketed by
+ * HIP events on the call's stream.  ucf_plan_kernel_times waits for the brackets of the last such call and returns, in
+ * launch order, duration [ms] and name of each kernel (names as rocprofv3 prints them, without the argument list);
+ * ucf_plan_kernel_ms returns the longest one (the dominant kernel of the path). */
 int ucf_plan_set_timing(ucf_plan* plan, int enable);
+int ucf_plan_kernel_times(ucf_plan* plan, int cap, double* ms, const char** names, int* n);
 int ucf_plan_kernel_ms(ucf_plan* plan, double* ms, const char** kernel_name);
+
+/* Size the workspaces of `stream` (hipStream_t as void*, NULL = default stream) for calls to come -- a grid of nt x nr
+ * points (0 x 0: none) and / or a point list of npts points (0: none), nz depths each -- so that the *_device entry
+ * points allocate nothing afterwards.  ucf_plan_alloc_count: device allocations made so far on behalf of calls. */
+int ucf_plan_reserve(ucf_plan* plan, int nt, int nr, int npts, int nz, void* stream);
+long long ucf_plan_alloc_count(const ucf_plan* plan);
+
+/* sha256 (first 16 hex digits) of the kernel and host sources this library was built from: measurement files under
+ * profiles/ carry it, and bench.py refuses a profile whose id differs from the library it runs. */
+const char* ucf_build_id(void);
 
 /* ---- host-side helpers that the reference computes in read_input ---- */
 int ucf_logspace(int lo, int hi, int n, double* out);                   /* utility.f90:51-57 */
@@ -163,7 +185,9 @@ int ucf_drawdown_batch(ucf_plan* plan, int npts,
                        double* h, double* dh, ucf_stats* stats /* may be NULL */);
 
 /* Same, all per-point arrays already resident in HBM; asynchronous on `stream`
- * (a hipStream_t passed as void*; NULL = default stream).  `d_stats` may be NULL. */
+ * (a hipStream_t passed as void*; NULL = default stream).  `d_stats` may be NULL.
+ * Preconditions the library cannot check on device-resident inputs: 1 <= sv[i] <= nj0z - nacc (sv indexes the
+ * J0-zero table; the host entry points check it and return UCF_ERR_BAD_ARGUMENT). */
 int ucf_drawdown_batch_device(ucf_plan* plan, int npts,
                               const double* d_tD, const double* d_rD, const int* d_sv,
                               int nz, const double* zD, const int* zLay,
@@ -178,6 +202,32 @@ int ucf_drawdown_grid(ucf_plan* plan, int nt, const double* tD, const int* sv, i
 int ucf_drawdown_grid_device(ucf_plan* plan, int nt, const double* d_tD, const int* d_sv, int nr, const double* d_rD,
                              int nz, const double* zD, const int* zLay, double* d_h, double* d_dh,
                              ucf_stats* d_stats, void* stream);
+/* (device-resident sv of a grid must lie in the plan's split range [min(j0s), max(j0s)]: it selects a row of the
+ *  per-radius abscissa table; ucf_split_vector produces such values and ucf_drawdown_grid checks them) */
+
+/* ---- the sweep on several GPUs.  Every (t,r) point is independent; the shard axis is the reference's
+ * own serial loop nest (do i = 1,nt / do k = 1,nr, driver.f90:100,113): the flattened index i*nr + k is cut into
+ * `world` contiguous blocks of whole time rows, B = ceil(nt / world) rows each (the last ones may be short or empty),
+ * so that a shard is itself a product grid and its results are one contiguous slice of [nt][nr][nz].
+ * No data-path collective; the only exchange is the final gather of the slices. */
+int ucf_shard_rows(int nt, int world, int rank, int* lo, int* hi);     /* rows [lo, hi) of shard `rank`; no GPU needed */
+
+/* One process per GPU (the bench, RCCL): the rank computes ITS rows of the sweep and leaves them at their place in the
+ * full-size device arrays d_h, d_dh [world*B][nr][nz] (d_tD, d_sv: all nt rows), so that an IN-PLACE all-gather of
+ * B*nr*nz doubles per rank (ncclAllGather with sendbuff = recvbuff + rank*count; torch.distributed
+ * all_gather_into_tensor on a view) completes the arrays on every rank.  Asynchronous on `stream`. */
+int ucf_drawdown_grid_shard_device(ucf_plan* plan, int rank, int world, int nt, const double* d_tD, const int* d_sv,
+                                   int nr, const double* d_rD, int nz, const double* zD, const int* zLay,
+                                   double* d_h, double* d_dh, ucf_stats* d_stats, void* stream);
+
+/* One process driving ngpu devices (the Fortran host): plans[g] was created with device g current (ucf_plan_create
+ * binds a plan to the current HIP device) from the same parameters.  Host arrays in and out like ucf_drawdown_grid;
+ * shard g runs on plans[g]'s device on a stream of its own, all devices at once, and the gather is each device's
+ * copy of its slice straight into rows lo..hi of h and dh (one PCIe/xGMI transfer per device: staging the slices
+ * through one GPU first would only add a hop).  stats: summed over the shards.  ngpu = 1 is ucf_drawdown_grid. */
+int ucf_drawdown_grid_multi(ucf_plan* const* plans, int ngpu, int nt, const double* tD, const int* sv, int nr,
+                            const double* rD, int nz, const double* zD, const int* zLay, double* h, double* dh,
+                            ucf_stats* stats);
 
 /* Parameter-batched evaluation for inversion / fitting (the tool's real use,
  * reference README.md:45-56): the SAME observation points -- dimensional times t[npts], radii r[npts],

@@ -24,3 +24,26 @@ def oracle():
 def oracle_quad():
     from oracle_lib import Oracle
     return Oracle(quad=True)
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _parity_report():
+    """after a GPU session: the slack every parity gate used (tests/test_gpu_parity.py::PARITY) as JSON"""
+    yield
+    try:
+        import json
+        import test_gpu_parity
+        if not test_gpu_parity.PARITY:
+            return
+        out = os.environ.get("UCF_PARITY_OUT", os.path.join(ROOT, "gpurun_out", "parity_r02.json"))
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        from unconfined_amd import engine
+        rep = {"build_id": engine.build_id(),
+               "what": "worst |err| / bound over all rows and radii of a deck, per gate and flavour (1.0 = the gate is exhausted); "
+                       "gates: tests/test_gpu_parity.py (vs_binary128_truth = gate 1, vs_reference_out = gate 2), "
+                       "tests/test_gpu_contract.py (f4_parameter_batch)",
+               "gates": test_gpu_parity.PARITY}
+        with open(out, "w") as f:
+            json.dump(rep, f, indent=1, sort_keys=True)
+    except Exception as exc:      # a report, not a test
+        print(f"[parity report] not written: {exc}")

@@ -1,0 +1,251 @@
+"""The contract of include/ucf.h beyond the numbers: concurrent use of one plan (per-stream workspaces), no allocation
+or synchronisation in the *_device entries once the workspaces exist, capture into a hipGraph, the multi-GPU entry
+points, and the parameter-batched entry against the oracle."""
+import threading
+
+import numpy as np
+import pytest
+
+from golden_util import load_deck, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def engine():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from unconfined_amd import engine as e
+    return e
+
+
+def _grid_inputs(plan, nt, nr, lo=-1.0, hi=4.0):
+    tD = 10.0 ** np.linspace(lo, hi, nt)
+    return tD, plan.split_vector(tD), 10.0 ** np.linspace(-1.0, 0.9, nr)
+
+
+@pytest.mark.parametrize("mode", ["fast", "faithful"])
+def test_two_threads_two_streams_one_plan(engine, mode):
+    """ucf.h: calls on one plan from several host threads, each on its own stream, share nothing: every thread
+    reproduces the bits of the same call made alone, whatever the other thread is doing (different sizes, so that
+    shared scratch would be resized under the other call's kernels)"""
+    import torch
+    dk, ts, P = load_deck("neuman74_partpen")
+    plan = engine.Plan(P, mode=mode)
+    zD = np.array([0.3, 0.91]); zl = plan.zlay(zD)
+    dev = torch.device("cuda:0")
+    jobs = []
+    for nt, nr in ((192, 9), (320, 5), (64, 30)):
+        tD, sv, rD = _grid_inputs(plan, nt, nr)
+        ref = plan.drawdown_grid(tD, sv, rD, zD, zl)
+        jobs.append((nt, nr, torch.tensor(tD, device=dev), torch.tensor(sv, dtype=torch.int32, device=dev), torch.tensor(rD, device=dev), ref))
+    # a point list too (lane = point layout, device-side ordering by radius)
+    rng = np.random.default_rng(4)
+    n = 700
+    tDl = 10.0 ** rng.uniform(-1, 3, n); rDl = 10.0 ** rng.uniform(-1, 1, n); svl = plan.split_vector(tDl)
+    ref_list = plan.drawdown(tDl, rDl, svl, zD, zl)
+    torch.cuda.synchronize()
+    errors = []
+
+    def grid_worker(job, reps):
+        nt, nr, d_t, d_s, d_r, ref = job
+        s = torch.cuda.Stream(device=dev)
+        out = torch.zeros(2, nt * nr * 2, dtype=torch.float64, device=dev)
+        for _ in range(reps):
+            out.zero_()
+            s.wait_stream(torch.cuda.current_stream())
+            plan.drawdown_grid_device(nt, d_t.data_ptr(), d_s.data_ptr(), nr, d_r.data_ptr(), zD, zl, out[0].data_ptr(), out[1].data_ptr(),
+                                      stream=s.cuda_stream)
+            s.synchronize()
+            h = out[0].cpu().numpy().reshape(nt, nr, 2); dh = out[1].cpu().numpy().reshape(nt, nr, 2)
+            if not (np.array_equal(h, ref[0], equal_nan=True) and np.array_equal(dh, ref[1], equal_nan=True)):
+                errors.append(("grid", nt, nr))
+
+    def list_worker(reps):
+        s = torch.cuda.Stream(device=dev)
+        d_t = torch.tensor(tDl, device=dev); d_r = torch.tensor(rDl, device=dev); d_s = torch.tensor(svl, dtype=torch.int32, device=dev)
+        out = torch.zeros(2, n * 2, dtype=torch.float64, device=dev)
+        torch.cuda.synchronize()
+        for _ in range(reps):
+            plan.drawdown_device(n, d_t.data_ptr(), d_r.data_ptr(), d_s.data_ptr(), zD, zl, out[0].data_ptr(), out[1].data_ptr(), stream=s.cuda_stream)
+            s.synchronize()
+            if not (np.array_equal(out[0].cpu().numpy().reshape(n, 2), ref_list[0], equal_nan=True) and
+                    np.array_equal(out[1].cpu().numpy().reshape(n, 2), ref_list[1], equal_nan=True)):
+                errors.append(("list",))
+
+    th = [threading.Thread(target=grid_worker, args=(j, 6)) for j in jobs] + [threading.Thread(target=list_worker, args=(6,))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=600)
+    assert not errors, errors
+    # host entry points from two threads at once (they share the default stream: serialised, still correct)
+    res = {}
+
+    def host_worker(k):
+        nt, nr = jobs[k][0], jobs[k][1]
+        tD, sv, rD = _grid_inputs(plan, nt, nr)
+        res[k] = plan.drawdown_grid(tD, sv, rD, zD, zl)
+    th = [threading.Thread(target=host_worker, args=(k,)) for k in (0, 1)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=600)
+    for k in (0, 1):
+        assert np.array_equal(res[k][0], jobs[k][5][0], equal_nan=True) and np.array_equal(res[k][1], jobs[k][5][1], equal_nan=True)
+
+
+def test_device_entries_do_not_allocate_after_reserve(engine):
+    """ucf_plan_reserve sizes the workspaces; after it (or after a first call of the same size) the *_device entries
+    allocate nothing, on any layout"""
+    import torch
+    dk, ts, P = load_deck("c2_neuman74_fullpen")
+    dev = torch.device("cuda:0")
+    for mode in ("fast", "faithful"):
+        plan = engine.Plan(P, mode=mode)
+        zD = np.array([0.91]); zl = plan.zlay(zD)
+        s = torch.cuda.Stream(device=dev)
+        for nt, nr in ((256, 12), (40, 20)):                  # lane = time, and a grid expanded into its point list
+            tD, sv, rD = _grid_inputs(plan, nt, nr)
+            d_t = torch.tensor(tD, device=dev); d_s = torch.tensor(sv, dtype=torch.int32, device=dev); d_r = torch.tensor(rD, device=dev)
+            out = torch.zeros(2, nt * nr, dtype=torch.float64, device=dev)
+            torch.cuda.synchronize()
+            plan.reserve(nt=nt, nr=nr, nz=1, stream=s.cuda_stream)
+            n0 = plan.alloc_count()
+            assert n0 > 0
+            for _ in range(2):
+                plan.drawdown_grid_device(nt, d_t.data_ptr(), d_s.data_ptr(), nr, d_r.data_ptr(), zD, zl, out[0].data_ptr(), out[1].data_ptr(), stream=s.cuda_stream)
+                assert plan.alloc_count() == n0, (mode, nt, nr)
+            s.synchronize()
+            ref = plan.drawdown_grid(tD, sv, rD, zD, zl)
+            assert np.array_equal(out[0].cpu().numpy().reshape(nt, nr, 1), ref[0], equal_nan=True)
+        # a point list: first call allocates, the second of the same size does not
+        n = 600
+        tD = 10.0 ** np.linspace(-1, 3, n); rD = np.full(n, 0.7); sv = plan.split_vector(tD)
+        d_t = torch.tensor(tD, device=dev); d_r = torch.tensor(rD, device=dev); d_s = torch.tensor(sv, dtype=torch.int32, device=dev)
+        out = torch.zeros(2, n, dtype=torch.float64, device=dev)
+        torch.cuda.synchronize()
+        plan.drawdown_device(n, d_t.data_ptr(), d_r.data_ptr(), d_s.data_ptr(), zD, zl, out[0].data_ptr(), out[1].data_ptr(), stream=s.cuda_stream)
+        n1 = plan.alloc_count()
+        plan.drawdown_device(n, d_t.data_ptr(), d_r.data_ptr(), d_s.data_ptr(), zD, zl, out[0].data_ptr(), out[1].data_ptr(), stream=s.cuda_stream)
+        assert plan.alloc_count() == n1
+        s.synchronize()
+
+
+def test_grid_call_can_be_captured_into_a_graph(engine):
+    """no synchronisation, no allocation: after ucf_plan_reserve a grid call records into a hipGraph and replays"""
+    import torch
+    dk, ts, P = load_deck("c2_neuman74_fullpen")
+    dev = torch.device("cuda:0")
+    plan = engine.Plan(P, mode="fast")
+    zD = np.array([0.91]); zl = plan.zlay(zD)
+    nt, nr = 256, 16
+    tD, sv, rD = _grid_inputs(plan, nt, nr)
+    ref = plan.drawdown_grid(tD, sv, rD, zD, zl)
+    d_t = torch.tensor(tD, device=dev); d_s = torch.tensor(sv, dtype=torch.int32, device=dev); d_r = torch.tensor(rD, device=dev)
+    out = torch.zeros(2, nt * nr, dtype=torch.float64, device=dev)
+    s = torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize()
+    plan.reserve(nt=nt, nr=nr, nz=1, stream=s.cuda_stream)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        g.capture_begin()
+        plan.drawdown_grid_device(nt, d_t.data_ptr(), d_s.data_ptr(), nr, d_r.data_ptr(), zD, zl, out[0].data_ptr(), out[1].data_ptr(),
+                                  stream=torch.cuda.current_stream().cuda_stream)
+        g.capture_end()
+    for _ in range(2):
+        out.zero_()
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(out[0].cpu().numpy().reshape(nt, nr, 1), ref[0], equal_nan=True)
+        assert np.array_equal(out[1].cpu().numpy().reshape(nt, nr, 1), ref[1], equal_nan=True)
+
+
+@pytest.mark.parametrize("name", ["neuman74_partpen", "c3_moench", "hantush_lay3"])
+def test_grid_multi_equals_single(engine, name):
+    """ucf_drawdown_grid_multi: the sweep cut into row blocks (ucf_shard_rows) over several plans -- on this box all on
+    the one GPU, each with its own stream -- gives the single-plan result: bit for bit in the faithful flavour whatever
+    the block sizes, and in the fast flavour when the blocks keep the lane layout"""
+    dk, ts, P = load_deck(name)
+    single = engine.Plan(P, mode="faithful")
+    zD = np.array([0.2, 0.6, 0.97]); zl = single.zlay(zD)
+    for nplans, nt, nr in ((2, 70, 7), (3, 64, 5), (4, 3, 11)):
+        tD, sv, rD = _grid_inputs(single, nt, nr, -2.0, 3.0)
+        h0, d0, st0 = single.drawdown_grid(tD, sv, rD, zD, zl, with_stats=True)
+        plans = [engine.Plan(P, mode="faithful") for _ in range(nplans)]
+        h, d, st = engine.drawdown_grid_multi(plans, tD, sv, rD, zD, zl, with_stats=True)
+        assert np.array_equal(h, h0, equal_nan=True) and np.array_equal(d, d0, equal_nan=True), (nplans, nt, nr)
+        assert st == st0
+    fast = engine.Plan(P, mode="fast")
+    tD, sv, rD = _grid_inputs(fast, 256, 6)
+    h0, d0 = fast.drawdown_grid(tD, sv, rD, zD, zl)
+    h, d = engine.drawdown_grid_multi([engine.Plan(P, mode="fast") for _ in range(2)], tD, sv, rD, zD, zl)
+    assert np.array_equal(h, h0, equal_nan=True) and np.array_equal(d, d0, equal_nan=True)
+
+
+def test_shard_device_entry_fills_its_rows_in_place(engine):
+    """ucf_drawdown_grid_shard_device: rank g writes rows shard_rows(g) of the full-size arrays and nothing else; all
+    ranks together give the whole sweep"""
+    import torch
+    from unconfined_amd import sharding
+    dk, ts, P = load_deck("c2_neuman74_fullpen")
+    plan = engine.Plan(P, mode="fast")
+    dev = torch.device("cuda:0")
+    zD = np.array([0.91]); zl = plan.zlay(zD)
+    nt, nr, world = 300, 6, 4
+    tD, sv, rD = _grid_inputs(plan, nt, nr)
+    d_t = torch.tensor(tD, device=dev); d_s = torch.tensor(sv, dtype=torch.int32, device=dev); d_r = torch.tensor(rD, device=dev)
+    prow = sharding.padded_rows(nt, world)
+    full = torch.full((2, prow * nr), -7.0, dtype=torch.float64, device=dev)
+    s = torch.cuda.current_stream()
+    for rank in (2, 0):
+        plan.drawdown_grid_shard_device(rank, world, nt, d_t.data_ptr(), d_s.data_ptr(), nr, d_r.data_ptr(), zD, zl, full[0].data_ptr(), full[1].data_ptr(),
+                                        stream=s.cuda_stream)
+    torch.cuda.synchronize()
+    got = full.cpu().numpy().reshape(2, prow, nr)
+    for rank in range(world):
+        lo, hi = sharding.shard_rows(nt, world, rank)
+        blk = got[:, lo:hi]
+        if rank in (0, 2):
+            href, dref = plan.drawdown_grid(tD[lo:hi], sv[lo:hi], rD, zD, zl)
+            assert np.array_equal(blk[0], href[..., 0]) and np.array_equal(blk[1], dref[..., 0])
+        else:
+            assert (blk == -7.0).all()
+    assert (got[:, nt:] == -7.0).all()
+
+
+def test_parameter_batched_sweep_vs_oracle(engine, oracle, oracle_quad):
+    """f4 against the oracle (not only against itself): every plan of a parameter batch, and a plan given new
+    parameters by ucf_plan_update, under the end-to-end gate |gpu - ref| <= max(1e-10, 20 x the reference's own
+    distance from the binary128 evaluation on these points)"""
+    from unconfined_amd.abi import params_from_deck
+    dk, ts, P0 = load_deck("neuman74_partpen")
+    decks = [dk.replace(Kr=dk.Kr * (0.6 + 0.3 * i), Sy=dk.Sy * (0.8 + 0.1 * i), kappa=dk.kappa * (0.5 + 0.4 * i), l=dk.l * (1.0 - 0.1 * i))
+             for i in range(4)]
+    params = [params_from_deck(d) for d in decks]
+    plans = [engine.Plan(p, mode="fast") for p in params]
+    t = 10.0 ** np.linspace(-1, 4, 22); r = np.full(22, 85.1); r[::3] = 30.0; r[1::5] = 300.0
+    z = np.array([145.7, 100.0])
+    h, dh = engine.drawdown_multi(plans, t, r, z)
+    upd = engine.Plan(params[0], mode="fast")
+    worst = {}
+    for k, pl in enumerate(plans):
+        D = oracle.nondim(params[k])
+        tD, rD, zD = t / D.Tc, r / D.Lc, z / D.Lc
+        sv = oracle.split_vector(list(dk.j0s), tD)
+        zl = oracle.zlay(D, zD)
+        ho, dho = oracle.batch(params[k], tD, rD, sv, zD, zl)
+        ht, dht = oracle_quad.batch(params[k], tD, rD, sv, zD, zl, threads=8)
+        upd.update(params[k])
+        hu, dhu = upd.drawdown(tD, rD, upd.split_vector(tD), zD, upd.zlay(zD))
+        for got, ref, truth, label in ((h[k] / D.Hc, ho, ht, "h"), (dh[k] / D.Hc, dho, dht, "dh"), (hu, ho, ht, "h_update"), (dhu, dho, dht, "dh_update")):
+            floor = 1e-3 / D.Hc
+            err = rel_err(got, ref, floor)
+            noise = float(rel_err(ref, truth, floor).max())
+            bound = max(1e-10, 20.0 * noise)
+            assert err.max() <= bound, (k, label, float(err.max()), noise)
+            worst[label] = max(worst.get(label, 0.0), float(err.max() / bound))
+    import test_gpu_parity
+    test_gpu_parity.PARITY["f4_parameter_batch"] = {"worst_err_over_bound": worst}

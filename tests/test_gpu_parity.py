@@ -30,12 +30,23 @@ pytestmark = pytest.mark.gpu
 
 NAMES = deck_names()
 MODES = ["faithful", "fast"]
+# how much of every gate's slack is used: worst err / bound per deck x flavour, written to
+# gpurun_out/parity_r02.json when the session ends (tests/conftest.py) and kept under profiles/
+PARITY = {}
+
+
+def _record(gate, name, mode, label, ratio, **extra):
+    ent = PARITY.setdefault(gate, {}).setdefault(name, {}).setdefault(mode, {})
+    ent[label] = max(ent.get(label, 0.0), float(ratio))
+    for k, v in extra.items():
+        ent[f"{label}_{k}"] = max(ent.get(f"{label}_{k}", 0.0), float(v))
 
 
 @pytest.fixture(scope="module")
 def engine():
     import torch
-    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    if not torch.cuda.is_available():
+        pytest.skip("GPU tests need a GPU (run with -m gpu on the MI355X box)")
     from unconfined_amd import engine as e
     return e
 
@@ -205,6 +216,8 @@ def test_end_to_end_vs_binary128_truth(engine, oracle, name, mode):
             # the max over ~100 points of a 1e5..1e7x amplified rounding error is heavy-tailed: the fast flavour
             # (different roundings in exp/sincos/sqrt) gets 20x the reference's own worst point, the faithful one 10x
             fmax = 10.0 if mode == "faithful" else 20.0
+            _record("vs_binary128_truth", name, mode, label + "_max", eg.max() / max(1e-10, fmax * er.max()), err=eg.max(), ref_err=er.max())
+            _record("vs_binary128_truth", name, mode, label + "_median", np.median(eg) / max(2e-12, fmed * np.median(er)), err=np.median(eg))
             assert eg.max() <= max(1e-10, fmax * er.max()), (name, mode, ir, label, float(eg.max()), float(er.max()))
             assert np.median(eg) <= max(2e-12, fmed * np.median(er)), (name, mode, ir, label, float(np.median(eg)), float(np.median(er)))
 
@@ -237,6 +250,7 @@ def test_end_to_end_vs_reference_outputs(engine, oracle, name, mode):
             sp = np.array([spread[max(0, i - k): i + k + 1].max() for i in range(len(spread))])
             bound = np.maximum(1e-10, 20.0 * np.maximum(sp, noise_t[label]))
             bad = err > bound
+            _record("vs_reference_out", name, mode, label, (err / bound).max(), err=err.max(), frac_within_1e_10=np.mean(err <= 1e-10))
             assert not bad.any(), (name, mode, ir, label, float(err.max()), float(spread.max()), noise_t[label], int(bad.sum()))
             if label == "h":
                 frac_ok.append(float(np.mean(err <= 1e-10)))

@@ -1,15 +1,18 @@
 // ucf_device.h -- the hot path on the device.  Included twice by ucf_kernels.hip
 // (UCF_FAST = 0 -> namespace ucf_faithful, UCF_FAST = 1 -> namespace ucf_fast).
 //
-// Mapping: one 64-lane wavefront owns one (t,r)
-// point; lane m owns Laplace sample p_m (2M+1 <= 64 of them); the wave walks the
-// Hankel abscissae serially, so the quadrature sums keep the reference's
-// summation order and need no cross-lane traffic.  Level sums / interval areas
-// live in LDS ([slot][lane] complex, 16 B per lane -> conflict-free b128
-// accesses); Richardson/Neville and Wynn-epsilon run per lane on those LDS
-// columns; only de Hoog's quotient-difference table needs neighbours (lane i+1),
-// which is a wave shuffle.  Nothing but 20 B in and 16*nz B out per point
-// touches HBM; the quadrature tables (< 10 KB) are read through the scalar cache.
+// Mapping: a 64-lane wavefront walks the Hankel abscissae of its work item serially, so the quadrature sums keep
+// the reference's summation order and need no cross-lane traffic.  What the 64 lanes are depends on the lane
+// layout (decode_item below): 64 consecutive TIMES of one radius and one Laplace index (grids, LAYOUT 1), 64 POINTS
+// of a list and one Laplace index (LAYOUT 3), or the Laplace samples p_m of one point (LAYOUT 0; chunks of 64 of
+// them for 2M+1 > 64, LAYOUT 2).  The abscissa loop has its own kernel (integrate_kernel / integrate_generic_kernel):
+// level sums in LDS ([slot][lane] complex, 16 B per lane -> conflict-free b128 accesses); when the loop is done the
+// level sums and the finished J0-interval areas go to the work item's STATE in HBM (1 KB coalesced per slot, ~15 KB
+// per item on the C2 settings -- deliberate traffic that buys the loop its occupancy).
+// finish_kernel reads the state back (Richardson/Neville and Wynn-epsilon per lane), writes the accelerated
+// transform totlap(r, z, m, t) (16 B each) and dehoog_*_kernel inverts it with lane = Laplace index: only de Hoog's
+// quotient-difference table needs neighbours (lane i+1: one DPP move per dword).  The abscissa tables (a, a J0(a rD)
+// per radius, written by abscissa_kernel) and the quadrature tables (< 10 KB) are read through the scalar cache.
 //
 // Every device function cites the reference lines it restates.
 
@@ -20,6 +23,8 @@ namespace UCF_NS {
 
 using namespace ucfm;
 
+#define UCF_STR_(x) #x
+#define UCF_STR(x) UCF_STR_(x)
 #define UCF_PI 3.14159265358979323846   /* 4*atan(1) in binary64 */
 #define UCF_EPS 2.220446049250313e-16
 
@@ -1728,14 +1733,15 @@ size_t state_bytes_per_item(const ucf_dev_params& dp)
 #endif
 
 // The transform stage for `nwork` work items of lane layout LAYOUT: [integrate kernel -> finish_kernel ->] point_kernel.
-// ev0/ev1 (optional) bracket the dominant kernel: the integrate kernel when there is one, else point_kernel.
+// tm (optional): every kernel of the stage is bracketed by HIP events on the launch stream (ucf_timers).
 template <int LAYOUT, bool MULTI>
 static int launch_transform_(const ucf_dev_params& dp, int nwork, int per_point, int nr, int nsv, int svmin, const double* d_tD,
                             const double* d_rD, const int* d_sv, const double* d_tab, double* d_h, double* d_dh,
                             ucf_stats* d_stats, int nt, int ir0, int nrc, double* d_totlap, double* d_glscr,
-                            double* d_state, int* d_ndone, void* stream, void* ev0, void* ev1,
+                            double* d_state, int* d_ndone, void* stream, ucf_timers* tm,
                             const ucf_dev_params* d_params, int ppp, int pbase)
 {
+    char kname[96];
     int* d_todo = d_ndone ? d_ndone + nwork : nullptr;     // [count | items]: the caller sizes d_ndone for 2 nwork + 1 ints
     const int fam = family_of(dp);
     if (fam < 0) return UCF_ERR_UNSUPPORTED;
@@ -1751,7 +1757,6 @@ static int launch_transform_(const ucf_dev_params& dp, int nwork, int per_point,
     dim3 grid((unsigned)((al || nwork < UCF_GRID_SLOTS) ? nwork : UCF_GRID_SLOTS)), block(UCF_WAVE);
     if (split) {
         (void)hipMemsetAsync(d_todo, 0, sizeof(int), s);
-        if (ev0) (void)hipEventRecord((hipEvent_t)ev0, s);
     }
 #if UCF_FAST
     if (kind == 1) {
@@ -1760,6 +1765,8 @@ static int launch_transform_(const ucf_dev_params& dp, int nwork, int per_point,
     do {                                                                                                       \
         if (ilds > 64 * 1024)                                                                                  \
             (void)hipFuncSetAttribute((const void*)integrate_kernel<F, LAYOUT, W, MULTI, FO, L3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ilds); \
+        std::snprintf(kname, sizeof(kname), UCF_STR(UCF_NS) "::integrate_kernel<%d, %d, %d, %s, %s, %s>", F, LAYOUT, W, MULTI ? "true" : "false", FO ? "true" : "false", L3 ? "true" : "false"); \
+        ucf_tm_mark(tm, kname, s);                                                                             \
         hipLaunchKernelGGL((integrate_kernel<F, LAYOUT, W, MULTI, FO, L3>), dim3((unsigned)nwork), block, ilds, s, dp, nwork, per_point, nr, nsv, svmin, \
                            d_tD, d_rD, d_sv, (const double2*)d_tab, nt, ir0, (double2*)d_state, d_ndone, d_todo, d_params, ppp, pbase); \
     } while (0)
@@ -1802,6 +1809,8 @@ static int launch_transform_(const ucf_dev_params& dp, int nwork, int per_point,
     do {                                                                                                       \
         if (ilds > 64 * 1024)                                                                                  \
             (void)hipFuncSetAttribute((const void*)integrate_generic_kernel<F, LAYOUT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ilds); \
+        std::snprintf(kname, sizeof(kname), UCF_STR(UCF_NS) "::integrate_generic_kernel<%d, %d>", F, LAYOUT);  \
+        ucf_tm_mark(tm, kname, s);                                                                             \
         hipLaunchKernelGGL((integrate_generic_kernel<F, LAYOUT>), dim3((unsigned)nwork), block, ilds, s, dp, nwork, per_point, nr, nsv, svmin, \
                            d_tD, d_rD, d_sv, (const double2*)d_tab, nt, ir0, (double2*)d_state, d_ndone);      \
     } while (0)
@@ -1818,9 +1827,7 @@ static int launch_transform_(const ucf_dev_params& dp, int nwork, int per_point,
 #undef UCF_LAUNCH_G
     }
     if (split) {
-        if (ev1) (void)hipEventRecord((hipEvent_t)ev1, s);
         if (hipGetLastError() != hipSuccess) return UCF_ERR_HIP;
-        ev0 = ev1 = nullptr;
         // tails of the completed items.  nacc <= UCF_WYNN_REGS: epsilon table in registers, LDS only for the level sums
         // and the Neville column; else the widest scratch part that still leaves 4 waves per CU (measured on C2:
         // 4.8 / 3.6 / 3.1 ms for parts of 16 / 32 / 64 lanes)
@@ -1835,6 +1842,8 @@ static int launch_transform_(const ucf_dev_params& dp, int nwork, int per_point,
     do {                                                                                                       \
         if (fl > 64 * 1024)                                                                                    \
             (void)hipFuncSetAttribute((const void*)finish_kernel<LAYOUT, PART, WR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fl); \
+        std::snprintf(kname, sizeof(kname), UCF_STR(UCF_NS) "::finish_kernel<%d, %d, %s>", LAYOUT, PART, WR ? "true" : "false"); \
+        ucf_tm_mark(tm, kname, s);                                                                             \
         hipLaunchKernelGGL((finish_kernel<LAYOUT, PART, WR>), dim3((unsigned)nwork), block, fl, s, dp, nwork, per_point, nr, nsv, svmin, \
                            d_tD, d_rD, d_sv, d_h, d_dh, d_stats, nt, ir0, (double2*)d_totlap, (const double2*)d_state, \
                            (const int*)d_ndone);                                                               \
@@ -1845,15 +1854,16 @@ static int launch_transform_(const ucf_dev_params& dp, int nwork, int per_point,
         else UCF_LAUNCH_F(16, false);
 #undef UCF_LAUNCH_F
         if (hipGetLastError() != hipSuccess) return UCF_ERR_HIP;
-        if (kind == 2) return UCF_OK;              // the generic evaluators leave nothing unfinished
+        if (kind == 2) { ucf_tm_close(tm, s); return UCF_OK; }      // the generic evaluators leave nothing unfinished
         // the unfinished ones (overflow regime): point_kernel over the list integrate_kernel left
         grid = dim3((unsigned)(nwork < 2048 ? nwork : 2048));
     }
-    if (ev0) (void)hipEventRecord((hipEvent_t)ev0, s);
 #define UCF_LAUNCH(F)                                                                                          \
     do {                                                                                                       \
         if (lds > 64 * 1024)                                                                                   \
             (void)hipFuncSetAttribute((const void*)point_kernel<F, LAYOUT, MULTI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        std::snprintf(kname, sizeof(kname), UCF_STR(UCF_NS) "::point_kernel<%d, %d, %s>", F, LAYOUT, MULTI ? "true" : "false"); \
+        ucf_tm_mark(tm, kname, s);                                                                             \
         hipLaunchKernelGGL((point_kernel<F, LAYOUT, MULTI>), grid, block, lds, s, dp, nwork, per_point, nr, nsv, svmin, d_tD, d_rD, d_sv, \
                            (const double2*)d_tab, d_h, d_dh, d_stats, nt, ir0, nrc, (double2*)d_totlap, (double2*)d_glscr,          \
                            (double2*)d_state, (const int*)d_ndone, (const int*)d_todo, d_params, ppp, pbase);  \
@@ -1867,7 +1877,7 @@ static int launch_transform_(const ucf_dev_params& dp, int nwork, int per_point,
     case 5: UCF_LAUNCH(5); break;
     }
 #undef UCF_LAUNCH
-    if (ev1) (void)hipEventRecord((hipEvent_t)ev1, s);
+    ucf_tm_close(tm, s);
     return hipGetLastError() == hipSuccess ? UCF_OK : UCF_ERR_HIP;
 }
 
@@ -1877,20 +1887,20 @@ template <int LAYOUT>
 static int launch_transform(const ucf_dev_params& dp, int nwork, int per_point, int nr, int nsv, int svmin, const double* d_tD,
                             const double* d_rD, const int* d_sv, const double* d_tab, double* d_h, double* d_dh,
                             ucf_stats* d_stats, int nt, int ir0, int nrc, double* d_totlap, double* d_glscr,
-                            double* d_state, int* d_ndone, void* stream, void* ev0, void* ev1,
+                            double* d_state, int* d_ndone, void* stream, ucf_timers* tm,
                             const ucf_dev_params* d_params = nullptr, int ppp = 1, int pbase = 0)
 {
 #if UCF_FAST
     if (d_params) {
         if (LAYOUT == 1 || !per_point) return UCF_ERR_BAD_ARGUMENT;      // (layouts 0, 2, 3)
         return launch_transform_<(LAYOUT == 1 ? 0 : LAYOUT), true>(dp, nwork, per_point, nr, nsv, svmin, d_tD, d_rD, d_sv, d_tab, d_h, d_dh, d_stats, nt,
-                                                                  ir0, nrc, d_totlap, d_glscr, d_state, d_ndone, stream, ev0, ev1, d_params, ppp, pbase);
+                                                                  ir0, nrc, d_totlap, d_glscr, d_state, d_ndone, stream, tm, d_params, ppp, pbase);
     }
 #else
     if (d_params) return UCF_ERR_UNSUPPORTED;
 #endif
     return launch_transform_<LAYOUT, false>(dp, nwork, per_point, nr, nsv, svmin, d_tD, d_rD, d_sv, d_tab, d_h, d_dh, d_stats, nt, ir0, nrc,
-                                            d_totlap, d_glscr, d_state, d_ndone, stream, ev0, ev1, nullptr, 1, 0);
+                                            d_totlap, d_glscr, d_state, d_ndone, stream, tm, nullptr, 1, 0);
 }
 
 #if UCF_TU_HAS(0)
@@ -1901,7 +1911,7 @@ int launch_points(const ucf_dev_params& dp, int npts, int per_point, int nr, int
                   const ucf_dev_params* d_params, int ppp, int pbase)
 {
     return launch_transform<0>(dp, npts, per_point, nr, nsv, svmin, d_tD, d_rD, d_sv, d_tab, d_h, d_dh, d_stats, 0, 0, 0,
-                               nullptr, d_glscr, d_state, d_ndone, stream, nullptr, nullptr, d_params, ppp, pbase);
+                               nullptr, d_glscr, d_state, d_ndone, stream, nullptr, d_params, ppp, pbase);
 }
 
 #endif
@@ -1910,7 +1920,7 @@ int launch_points(const ucf_dev_params& dp, int npts, int per_point, int nr, int
 // LAYOUT 1 (lane = time): transform kernel(s) over (radius chunk x time tiles x Laplace index), then de Hoog
 int launch_grid_transposed(const ucf_dev_params& dp, int nt, int nr, int ir0, int nrc, int svmin, const double* d_tD,
                            const double* d_rD, const double* d_tab, double* d_totlap, double* d_h, double* d_dh,
-                           ucf_stats* d_stats, void* stream, void* ev0, void* ev1, double* d_glscr, double* d_state,
+                           ucf_stats* d_stats, void* stream, ucf_timers* tm, double* d_glscr, double* d_state,
                            int* d_ndone)
 {
     hipStream_t s = (hipStream_t)stream;
@@ -1918,12 +1928,14 @@ int launch_grid_transposed(const ucf_dev_params& dp, int nt, int nr, int ir0, in
     const long long nwork = (long long)nrc * ntiles * dp.np;
     if (nwork > 0x7fffffffLL) return UCF_ERR_BAD_ARGUMENT;
     int rc = launch_transform<1>(dp, (int)nwork, 0, nr, 1, svmin, d_tD, d_rD, nullptr, d_tab, d_h, d_dh, d_stats, nt, ir0, nrc,
-                                 d_totlap, d_glscr, d_state, d_ndone, stream, ev0, ev1);
+                                 d_totlap, d_glscr, d_state, d_ndone, stream, tm);
     if (rc) return rc;
     const long long ntl = (long long)nrc * ((nt + UCF_DH_TILE - 1) / UCF_DH_TILE);
     const size_t dlds = 2 * (size_t)dp.np * (UCF_DH_TILE + 1) * sizeof(lds_c) + 2 * UCF_DH_TILE * sizeof(int);
+    ucf_tm_mark(tm, UCF_STR(UCF_NS) "::dehoog_tiles_kernel<1>", s);
     hipLaunchKernelGGL(dehoog_tiles_kernel<1>, dim3((unsigned)(ntl > 0x7fffffffLL ? 0x7fffffff : ntl)), dim3(UCF_WAVE), dlds, s, dp, nt, nr, ir0,
                        nrc, d_tD, (const double2*)d_totlap, d_h, d_dh, d_stats);
+    ucf_tm_close(tm, s);
     return hipGetLastError() == hipSuccess ? UCF_OK : UCF_ERR_HIP;
 }
 
@@ -1941,7 +1953,7 @@ int launch_points_lanes(const ucf_dev_params& dp, int npts, int ppp, const doubl
     const long long nwork = (long long)(npts / ppp) * ((ppp + UCF_WAVE - 1) / UCF_WAVE) * dp.np;
     if (nwork > 0x7fffffffLL) return UCF_ERR_BAD_ARGUMENT;
     int rc = launch_transform<3>(dp, (int)nwork, 1, ppp, 1, 0, d_tD, d_rD, d_sv, d_tab, d_h, d_dh, d_stats, npts, 0, 0, d_totlap, nullptr,
-                                 d_state, d_ndone, stream, nullptr, nullptr, d_params, ppp, pbase);
+                                 d_state, d_ndone, stream, nullptr, d_params, ppp, pbase);
     if (rc) return rc;
     const long long ntl = (npts + UCF_DH_TILE - 1) / UCF_DH_TILE;
     const size_t dlds = 2 * (size_t)dp.np * (UCF_DH_TILE + 1) * sizeof(lds_c) + 2 * UCF_DH_TILE * sizeof(int);
@@ -1964,7 +1976,7 @@ int launch_points_chunked(const ucf_dev_params& dp, int npts, int per_point, int
     const long long nwork = (long long)npts * nchunk;
     if (nwork > 0x7fffffffLL) return UCF_ERR_BAD_ARGUMENT;
     int rc = launch_transform<2>(dp, (int)nwork, per_point, nr, nsv, svmin, d_tD, d_rD, d_sv, d_tab, d_h, d_dh, d_stats, 0, 0, 0,
-                                 d_totlap, d_glscr, d_state, d_ndone, stream, nullptr, nullptr, d_params, ppp, pbase);
+                                 d_totlap, d_glscr, d_state, d_ndone, stream, nullptr, d_params, ppp, pbase);
     if (rc) return rc;
     hipLaunchKernelGGL(dehoog_points_kernel, dim3((unsigned)npts), dim3(UCF_WAVE), 0, s, dp, (long long)npts, 1, per_point, nr, 0, 0, d_tD,
                        (const double2*)d_totlap, d_h, d_dh, d_stats);

@@ -1,6 +1,9 @@
 // ucf_plan.h -- internal structures shared by the host API and the kernels.
 #pragma once
 #include "../../include/ucf.h"
+#include <cstdio>
+#include <mutex>
+#include <vector>
 
 #define UCF_WAVE 64
 #define UCF_MAX_R 16
@@ -42,49 +45,84 @@ struct ucf_dev_params {
     const double* sched;   // timeType = -n: [n] start times | [n] rate increments | final time | sum of increments
 };
 
+// HIP events around the kernels of the last single-chunk grid call issued through a workspace (measurement only):
+// bracket i = ev[2i] .. ev[2i+1] around the kernel called name[i].
+#define UCF_MAX_TIMED 8
+struct ucf_timers {
+    void* ev[2 * UCF_MAX_TIMED];     // hipEvent_t, created on first use
+    char name[UCF_MAX_TIMED][96];
+    int n;                           // brackets recorded by the last timed call
+    int open;                        // a bracket is open
+};
+// begin a bracket (closing the one before it); no-ops on a NULL timer set
+static inline void ucf_tm_close(ucf_timers* tm, void* stream)
+{
+    if (!tm || !tm->open) return;
+    (void)hipEventRecord((hipEvent_t)tm->ev[2 * (tm->n - 1) + 1], (hipStream_t)stream);
+    tm->open = 0;
+}
+static inline void ucf_tm_mark(ucf_timers* tm, const char* name, void* stream)
+{
+    if (!tm) return;
+    ucf_tm_close(tm, stream);
+    if (tm->n >= UCF_MAX_TIMED) return;
+    const int i = tm->n;
+    for (int k = 2 * i; k < 2 * i + 2; k++)
+        if (!tm->ev[k]) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return; tm->ev[k] = e; }
+    std::snprintf(tm->name[i], sizeof(tm->name[i]), "%s", name);
+    (void)hipEventRecord((hipEvent_t)tm->ev[2 * i], (hipStream_t)stream);
+    tm->n = i + 1;
+    tm->open = 1;
+}
+
+// Everything a call in flight writes.  A plan keeps one workspace per HIP stream that has called into it, so calls on
+// different streams never share scratch; calls that name the same stream are enqueued under the workspace's lock and
+// run in stream order.  Buffers only ever grow; a buffer that is outgrown is RETIRED (kept until ucf_plan_reserve /
+// ucf_plan_destroy), never freed while kernels may still read it -- no synchronisation inside the *_device entries.
+struct ucf_buffer {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+struct ucf_workspace {
+    void* stream = nullptr;
+    std::mutex mu;                 // held while a call enqueues its work on `stream`
+    ucf_buffer work;               // abscissa table: rows x nabs x (a, a*J0(a rD))
+    ucf_buffer totlap;             // accelerated transform totlap(t, r, z, m) of the lane = time / lane = point layouts, 16 B each
+    ucf_buffer glscr;              // finished J0-interval areas of the resident workgroups: [UCF_GRID_SLOTS][nacc][nz][64] complex
+    ucf_buffer expand;             // a grid expanded into the point list it stands for: tD | rD | sv per point
+    ucf_buffer sort;               // device-side ordering of a point list by radius: keys, permutation, staged inputs/outputs
+    ucf_buffer state;              // integrate kernel -> finish/point kernel: [items][(R+1+nacc)*nz][64] complex
+    ucf_buffer ndone;              // abscissae done per item | count of unfinished | unfinished items
+    ucf_buffer pblocks;            // parameter blocks of a parameter-batched launch (ucf_drawdown_multi)
+    std::vector<void*> retired;    // outgrown buffers
+    bool dry = false;              // ucf_plan_reserve: size the buffers, launch nothing
+    ucf_timers tm = {};
+    int tm_valid = 0;
+};
+
 struct ucf_plan {
-    ucf_params P;
-    ucf_derived D;
-    ucf_dev_params dev;        // zD/zLay/nz filled per call
-    int mode;                  // 0 faithful, 1 fast
-    int force_layout0;         // diagnostic: never use the lane = time layout
-    int timing;                // bracket the dominant kernel with events
-    void* ev0;                 // hipEvent_t
-    void* ev1;
-    int ev_valid;
-    const char* last_kernel;
-    int device;
-    double* d_tables;          // one allocation holding all tables
-    size_t tables_bytes;
-    size_t o_tsx, o_tsw, o_glx, o_glw, o_j0z, o_fde, o_sched;     // offsets (doubles) of the tables in it
+    ucf_params P = {};
+    ucf_derived D = {};
+    ucf_dev_params dev = {};   // zD/zLay/nz filled per call
+    int mode = 0;              // 0 faithful, 1 fast
+    int force_layout0 = 0;     // diagnostic: never use the lane = time layout
+    int timing = 0;            // bracket the kernels of single-chunk grid calls with events
+    int device = 0;
+    double* d_tables = nullptr;    // one allocation holding all tables
+    size_t tables_bytes = 0;
+    size_t o_tsx = 0, o_tsw = 0, o_glx = 0, o_glw = 0, o_j0z = 0, o_fde = 0, o_sched = 0;     // offsets (doubles) of the tables in it
     // host copies (for the accessor API)
-    double* h_j0z;
-    double* h_ts_x;
-    double* h_ts_w;            // [R][N]
-    double* h_gl_x;
-    double* h_gl_w;
-    int Nv[UCF_MAX_R];
-    // abscissa-table workspace (grown on demand, never shrunk)
-    double* d_work;
-    size_t work_bytes;
-    // LAYOUT 1 workspace: accelerated transform totlap(t, r, z, m), 16 B each
-    double* d_totlap;
-    size_t totlap_bytes;
-    // finished J0-interval areas of the resident workgroups: [UCF_GRID_SLOTS][nacc][nz][64] complex
-    double* d_glscr;
-    size_t glscr_bytes;
-    // a grid expanded into the point list it stands for (small time vectors): tD | rD | sv per point
-    double* d_expand;
-    size_t expand_points;
-    // device-side ordering of a point list by radius (ucf_drawdown_batch_device): keys, permutation, staged inputs/outputs
-    void* d_sort;
-    size_t sort_bytes;
-    // fast flavour: state of every work item between integrate_kernel and point_kernel
-    // [items][(R+1+nacc)*nz][64] complex, and the abscissae done per item
-    double* d_state;
-    size_t state_bytes;
-    int* d_ndone;
-    size_t ndone_items;
+    double* h_j0z = nullptr;
+    double* h_ts_x = nullptr;
+    double* h_ts_w = nullptr;      // [R][N]
+    double* h_gl_x = nullptr;
+    double* h_gl_w = nullptr;
+    int Nv[UCF_MAX_R] = {};
+    // per-stream workspaces (see ucf_workspace); `mu` guards the list and the counters
+    std::mutex mu;
+    std::vector<ucf_workspace*> ws;
+    ucf_workspace* last_timed = nullptr;
+    long long n_alloc = 0;         // device allocations made on behalf of calls (ucf_plan_alloc_count)
 };
 
 // launchers implemented in ucf_kernels.hip (one set per build flavour)
@@ -104,7 +142,7 @@ int launch_points_chunked(const ucf_dev_params& dp, int npts, int per_point, int
                   const ucf_dev_params* d_params = nullptr, int ppp = 1, int pbase = 0);
 int launch_grid_transposed(const ucf_dev_params& dp, int nt, int nr, int ir0, int nrc, int svmin, const double* d_tD,
                            const double* d_rD, const double* d_tab, double* d_totlap, double* d_h, double* d_dh,
-                           ucf_stats* d_stats, void* stream, void* ev0, void* ev1, double* d_glscr, double* d_state, int* d_ndone);
+                           ucf_stats* d_stats, void* stream, ucf_timers* tm, double* d_glscr, double* d_state, int* d_ndone);
 int launch_points_lanes(const ucf_dev_params& dp, int npts, int ppp, const double* d_tD, const double* d_rD, const int* d_sv,
                         const double* d_tab, double* d_totlap, double* d_h, double* d_dh, ucf_stats* d_stats, void* stream,
                         double* d_state, int* d_ndone, const ucf_dev_params* d_params = nullptr, int pbase = 0);
@@ -124,7 +162,7 @@ int launch_points_chunked(const ucf_dev_params& dp, int npts, int per_point, int
                   const ucf_dev_params* d_params = nullptr, int ppp = 1, int pbase = 0);
 int launch_grid_transposed(const ucf_dev_params& dp, int nt, int nr, int ir0, int nrc, int svmin, const double* d_tD,
                            const double* d_rD, const double* d_tab, double* d_totlap, double* d_h, double* d_dh,
-                           ucf_stats* d_stats, void* stream, void* ev0, void* ev1, double* d_glscr, double* d_state, int* d_ndone);
+                           ucf_stats* d_stats, void* stream, ucf_timers* tm, double* d_glscr, double* d_state, int* d_ndone);
 int launch_points(const ucf_dev_params& dp, int npts, int per_point, int nr, int nsv, int svmin, const double* d_tD,
                   const double* d_rD, const int* d_sv, const double* d_tab, double* d_h, double* d_dh,
                   ucf_stats* d_stats, void* stream, double* d_glscr, double* d_state, int* d_ndone,

@@ -80,6 +80,22 @@ class Plan:
         _libmod.check(self._lib.ucf_plan_kernel_ms(self._h, C.byref(ms), C.byref(name)))
         return ms.value, (name.value or b"").decode()
 
+    def kernel_times(self):
+        """[(kernel name, ms), ...] of every kernel of the last timed single-chunk grid call, in launch order"""
+        cap = 8
+        ms = (C.c_double * cap)()
+        names = (C.c_char_p * cap)()
+        n = C.c_int(0)
+        _libmod.check(self._lib.ucf_plan_kernel_times(self._h, cap, ms, names, C.byref(n)))
+        return [((names[i] or b"").decode(), ms[i]) for i in range(n.value)]
+
+    def reserve(self, nt: int = 0, nr: int = 0, npts: int = 0, nz: int = 1, stream: int = 0):
+        """size the workspaces of `stream` so that later *_device calls of these sizes allocate nothing"""
+        _libmod.check(self._lib.ucf_plan_reserve(self._h, int(nt), int(nr), int(npts), int(nz), stream or None))
+
+    def alloc_count(self) -> int:
+        return int(self._lib.ucf_plan_alloc_count(self._h))
+
     # ---- tables (read back for parity tests / headers)
     def j0z(self) -> np.ndarray:
         out = np.zeros(self.derived.nj0z)
@@ -165,6 +181,13 @@ class Plan:
         _libmod.check(self._lib.ucf_drawdown_grid_device(self._h, int(nt), d_tD, d_sv, int(nr), d_rD, len(zD), zD, zLay,
                                                          d_h, d_dh, d_stats or None, stream or None))
 
+    def drawdown_grid_shard_device(self, rank: int, world: int, nt: int, d_tD: int, d_sv: int, nr: int, d_rD: int, zD, zLay,
+                                   d_h: int, d_dh: int, stream: int = 0, d_stats: int = 0):
+        """this rank's rows (shard_rows) of the nt x nr sweep, written at their place in the full-size device arrays"""
+        zD, zLay = _f64(zD), _i32(zLay)
+        _libmod.check(self._lib.ucf_drawdown_grid_shard_device(self._h, int(rank), int(world), int(nt), d_tD, d_sv, int(nr), d_rD,
+                                                               len(zD), zD, zLay, d_h, d_dh, d_stats or None, stream or None))
+
     def drawdown_device(self, n: int, d_tD: int, d_rD: int, d_sv: int, zD, zLay, d_h: int, d_dh: int,
                         stream: int = 0, d_stats: int = 0):
         """asynchronous launch on device pointers (ints), e.g. torch tensors' data_ptr()"""
@@ -179,6 +202,32 @@ class Plan:
         out = np.zeros((len(a), len(zD), p.shape[0], 2))
         _libmod.check(self._lib.ucf_eval_samples(self._h, len(a), a, float(rD), p.shape[0], p, len(zD), zD, zLay, out))
         return out
+
+
+def shard_rows(nt: int, world: int, rank: int) -> Tuple[int, int]:
+    """rows [lo, hi) of the nt-row sweep that shard `rank` of `world` owns (ucf_shard_rows; needs no GPU)"""
+    lo, hi = C.c_int(0), C.c_int(0)
+    _libmod.check(_libmod.load().ucf_shard_rows(int(nt), int(world), int(rank), C.byref(lo), C.byref(hi)))
+    return lo.value, hi.value
+
+
+def build_id() -> str:
+    return (_libmod.load().ucf_build_id() or b"").decode()
+
+
+def drawdown_grid_multi(plans, tD, sv, rD, zD, zLay, with_stats: bool = False):
+    """one sweep on len(plans) devices driven by this process (ucf_drawdown_grid_multi): h, dh [nt, nr, nz]"""
+    lib = _libmod.load()
+    tD, sv, rD, zD, zLay = _f64(tD), _i32(sv), _f64(rD), _f64(zD), _i32(zLay)
+    nt, nr, nz = len(tD), len(rD), len(zD)
+    arr = (C.c_void_p * len(plans))(*[p._h for p in plans])
+    h = np.zeros((nt, nr, nz))
+    dh = np.zeros((nt, nr, nz))
+    st = UcfStats()
+    _libmod.check(lib.ucf_drawdown_grid_multi(arr, len(plans), nt, tD, sv, nr, rD, nz, zD, zLay, h, dh, C.byref(st) if with_stats else None))
+    if with_stats:
+        return h, dh, {k: getattr(st, k) for k, _ in UcfStats._fields_}
+    return h, dh
 
 
 def drawdown_multi(plans, t, r, z, dimensionless: bool = False):

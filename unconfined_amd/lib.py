@@ -23,7 +23,9 @@ _ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
 EXPORTS = [
     "ucf_version", "ucf_last_error", "ucf_status_string",
     "ucf_plan_create", "ucf_plan_destroy", "ucf_plan_update", "ucf_plan_derived", "ucf_plan_j0z", "ucf_plan_tanh_sinh",
-    "ucf_plan_gauss_lobatto", "ucf_plan_set_mode", "ucf_plan_set_timing", "ucf_plan_kernel_ms",
+    "ucf_plan_gauss_lobatto", "ucf_plan_set_mode", "ucf_plan_set_timing", "ucf_plan_kernel_ms", "ucf_plan_kernel_times",
+    "ucf_plan_reserve", "ucf_plan_alloc_count", "ucf_build_id",
+    "ucf_shard_rows", "ucf_drawdown_grid_shard_device", "ucf_drawdown_grid_multi",
     "ucf_logspace", "ucf_linspace", "ucf_zlay", "ucf_split_vector",
     "ucf_drawdown_batch", "ucf_drawdown_batch_device", "ucf_drawdown_grid", "ucf_drawdown_grid_device",
     "ucf_drawdown_multi", "ucf_screen_average",
@@ -77,6 +79,15 @@ def load() -> C.CDLL:
     lib.ucf_plan_set_mode.argtypes = [vp, C.c_int]
     lib.ucf_plan_set_timing.argtypes = [vp, C.c_int]
     lib.ucf_plan_kernel_ms.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_char_p)]
+    lib.ucf_plan_kernel_times.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_char_p), C.POINTER(C.c_int)]
+    lib.ucf_plan_reserve.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]
+    lib.ucf_plan_alloc_count.argtypes = [vp]
+    lib.ucf_plan_alloc_count.restype = C.c_longlong
+    lib.ucf_build_id.restype = C.c_char_p
+    lib.ucf_shard_rows.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.ucf_drawdown_grid_shard_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp, C.c_int, _dp, _ip, vp, vp, vp, vp]
+    lib.ucf_drawdown_grid_multi.argtypes = [C.POINTER(vp), C.c_int, C.c_int, _dp, _ip, C.c_int, _dp, C.c_int, _dp, _ip, _dp, _dp,
+                                            C.POINTER(UcfStats)]
     lib.ucf_logspace.argtypes = [C.c_int, C.c_int, C.c_int, _dp]
     lib.ucf_linspace.argtypes = [C.c_double, C.c_double, C.c_int, _dp]
     lib.ucf_zlay.argtypes = [vp, C.c_int, _dp, _ip]
