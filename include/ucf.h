@@ -75,8 +75,9 @@ typedef struct ucf_params {
     int model;            /* 0 Theis, 1 Hantush, 2 Hantush+storage, 3 Moench, 4 Malama full, 5 Malama partial, 6 Mishra/Neuman */
     int MNtype;           /* model 6: 0 naive (ARB, unsupported), 1 Malama, 2 finite difference */
     int order;            /* model 6 / MNtype 2: FD nodes in the vadose zone */
-    int timeType;         /* pumping-rate time behaviour (time.f90:46): 1..8, or -n = n-step piecewise-constant
-                             schedule (-1..-100) whose 2n+1 parameters are in timeParExt */
+    int timeType;         /* pumping-rate time behaviour (time.f90:46): 1..8; -n (-1..-100) = n-step piecewise-CONSTANT
+                             schedule; -(100+n) (-101..-200) = n-segment piecewise-LINEAR schedule (time.f90:97-122);
+                             the 2n+1 parameters of either are in timeParExt */
     double timePar[2];
     double Q;             /* pumping rate [L^3/T] */
     double l, d;          /* depth to screen bottom / top from aquifer top [L] */
@@ -99,7 +100,12 @@ typedef struct ucf_params {
     int _pad1;
     double alpha, tol;    /* de Hoog abscissa of convergence, tolerance */
     double rwobs, sF;     /* observation well radius / shape factor (model 2) */
-    /* timeType = -n: tpar(1:n) step start times, tpar(n+1) final time, tpar(n+2:2n+1) rates (types.f90:66-70) */
+    /* piecewise constant: tpar(1:n) step start times, tpar(n+1) final time, tpar(n+2:2n+1) rates (types.f90:66-70).
+     * piecewise linear: tpar(1:n) knot times t_1 < ... < t_n, tpar(n+1) = t_f, tpar(n+2:2n+1) = the rate at t_2, ..., t_n,
+     * t_f; the rate is 0 up to t_1, continuous ("no jumps", time.f90:98), linear between knots, constant after t_f.
+     * (The reference reads the n rates as y(t_1..t_n) and then indexes y(n+1), one past its array, time.f90:101,115:
+     * its transform only ever uses rate DIFFERENCES, i.e. it assumes a rate that starts from 0 at t_1 -- the reading
+     * here is the one under which every parameter is used and nothing is read out of bounds) */
     double timeParExt[2 * UCF_MAX_SCHEDULE + 1];
 } ucf_params;
 
@@ -135,7 +141,9 @@ const char* ucf_status_string(int status);
 
 /* ---- plan: replaces read_input's numerical half + the `first`-time setup in the driver
  * (driver_io.f90:531-567,628-647; driver.f90:79-91,121-126,138-151,179-183). ---- */
-int ucf_plan_create(const ucf_params* P, ucf_plan** out);
+int ucf_plan_create(const ucf_params* P, ucf_plan** out);        /* bound to the HIP device that is current */
+int ucf_plan_create_on(const ucf_params* P, int device, ucf_plan** out);   /* bound to HIP device `device` (0-based) */
+int ucf_device_count(int* n);                                    /* UCF_ERR_NO_DEVICE if there is none */
 void ucf_plan_destroy(ucf_plan* plan);
 /* New hydraulic / geometric / schedule parameters for an existing plan (parameter estimation: thousands of
  * parameter sets, one set of numerical settings): everything that depends on them (driver_io.f90:531-567 and the
@@ -144,6 +152,9 @@ void ucf_plan_destroy(ucf_plan* plan);
  * not change: UCF_ERR_BAD_ARGUMENT otherwise.  Microseconds instead of the ~0.3 ms of ucf_plan_create. */
 int ucf_plan_update(ucf_plan* plan, const ucf_params* P);
 int ucf_plan_derived(const ucf_plan* plan, ucf_derived* out);
+/* the same quantities without a plan (host arithmetic only, no GPU needed): read_input's checks (driver_io.f90:88-333)
+ * and its non-dimensionalisation (:531-567) */
+int ucf_nondimensionalise(const ucf_params* P, ucf_derived* out);
 int ucf_plan_j0z(const ucf_plan* plan, int n, double* j0z);             /* driver_io.f90:628-647 */
 int ucf_plan_tanh_sinh(const ucf_plan* plan, int level /*1..R*/, int n, double* w, double* x_unit /* tanh(u2)+1, level R only, may be NULL */);
 int ucf_plan_gauss_lobatto(const ucf_plan* plan, int n, double* x, double* w);

@@ -303,6 +303,21 @@ void ucfo_pvalues(double tee, int M, double alpha, double tol, double* p_re_im)
     free(p);
 }
 
+/* counts of the reference's in-band rules taken since ucfo_stats_reset (same six counters as ucf_stats, include/ucf.h):
+ * 0 nan_scrubbed (invlap.f90:71-74, samples), 1 zero_vectors (invlap.f90:69,139), 2 wynn_truncated, 3 wynn_sentinel,
+ * 4 wynn_early_exit (integration.f90:140-177), 5 wynn_all_zero (driver.f90:209).  Only point_R counts (g_count_on). */
+static long long g_cnt[6];
+static int g_count_on = 0;
+#pragma omp threadprivate(g_count_on)
+static void cnt_add(int which, long long n)
+{
+    if (!g_count_on || n == 0) return;
+#pragma omp atomic
+    g_cnt[which] += n;
+}
+void ucfo_stats_reset(void) { for (int i = 0; i < 6; i++) g_cnt[i] = 0; }
+void ucfo_stats_get(long long* out) { for (int i = 0; i < 6; i++) out[i] = g_cnt[i]; }
+
 /* invlap.f90:46-141 with nt = 1 (scalar wrapper :143-152) */
 static R dehoog_R(int M, R alpha, R tol, R t, R tee, const C* fp)
 {
@@ -316,7 +331,8 @@ static R dehoog_R(int M, R alpha, R tol, R t, R tee, const C* fp)
         if (m > mx) mx = m;
     }
     (void)anynan;
-    if (!(mx > R_TINY)) return RC(0.0);                                   /* :69,139 */
+    if (!(mx > R_TINY)) { cnt_add(1, 1); return RC(0.0); }                /* :69,139 */
+    { long long nn = 0; for (int i = 0; i <= n2; i++) nn += c_isnan_part(fp[i]) ? 1 : 0; cnt_add(0, nn); }
 
     C* ff = (C*)malloc(sizeof(C) * (n2 + 1));
     C* e = (C*)calloc((size_t)(n2 + 1) * (M + 1), sizeof(C));             /* e(0:2M,0:M) */
@@ -721,12 +737,25 @@ static void mdl_fill(mdl* m, const ucf_params* P, const ucf_derived* D)
     m->model = P->model; m->MNtype = P->MNtype; m->order = P->order;
     m->timeType = P->timeType; m->MoenchM = P->MoenchM;
     m->timePar[0] = (R)P->timePar[0]; m->timePar[1] = (R)P->timePar[1];
-    if (P->timeType < 0 && P->timeType >= -UCF_MAX_SCHEDULE) {         /* time.f90:83-89 */
-        const int n = -P->timeType;
-        double qprev = 0.0, sum = 0.0;
+    if (P->timeType < 0 && P->timeType >= -(100 + UCF_MAX_SCHEDULE)) {
+        /* time.f90:83-89 piecewise constant: rate increments; time.f90:99-113 piecewise linear (timeType <= -101):
+         * slope increments W_k - W_{k-1}, W_k = (y_{k+1} - y_k)/(t_{k+1} - t_k).  The reference unpacks the n rates into
+         * y(1:n) and then reads y(n+1), one past the array (:101,113); its transform uses rate differences only, i.e. a
+         * rate that starts from 0 at t_1 ("no jumps", :98).  Restated in bounds: y(t_1) = 0 and the n parameters are the
+         * rates at t_2..t_n, t_f (every parameter used, nothing read out of bounds). */
+        const int linear = P->timeType <= -101;
+        const int n = linear ? -P->timeType - 100 : -P->timeType;
+        double prev = 0.0, sum = 0.0, yprev = 0.0;
         for (int k = 0; k < n; k++) {
-            const double dq = P->timeParExt[n + 1 + k] - qprev;
-            qprev = P->timeParExt[n + 1 + k];
+            double cur = P->timeParExt[n + 1 + k];
+            if (linear) {
+                const double denom = P->timeParExt[k + 1] - P->timeParExt[k];
+                const double w = (cur - yprev) / denom;
+                yprev = cur;
+                cur = w;
+            }
+            const double dq = cur - prev;
+            prev = cur;
             m->sched_t[k] = (R)P->timeParExt[k];
             m->sched_dq[k] = (R)dq;
             sum = (k == 0) ? dq : sum + dq;
@@ -748,14 +777,16 @@ static void mdl_fill(mdl* m, const ucf_params* P, const ucf_derived* D)
 static C lap_time(const mdl* m, C p)
 {
     const R t1 = m->timePar[0], t2 = m->timePar[1];
-    if (m->timeType < 0 && m->timeType >= -UCF_MAX_SCHEDULE) {           /* :81-95 piecewise-constant rate */
-        const int n = -m->timeType;
+    if (m->timeType < 0 && m->timeType >= -(100 + UCF_MAX_SCHEDULE)) {   /* :81-95 piecewise-constant, :97-122 piecewise-linear rate */
+        const int linear = m->timeType <= -101;
+        const int n = linear ? -m->timeType - 100 : -m->timeType;
         C sum = c_make(RC(0.0), RC(0.0));
         for (int k = 0; k < n; k++) {
             C term = c_rscale(m->sched_dq[k], c_exp(c_rscale(-m->sched_t[k], p)));
             sum = (k == 0) ? term : c_add(sum, term);
         }
-        return c_div(c_sub(sum, c_rscale(m->sched_sum, c_exp(c_rscale(-m->sched_tf, p)))), p);
+        C num = c_sub(sum, c_rscale(m->sched_sum, c_exp(c_rscale(-m->sched_tf, p))));
+        return c_div(num, linear ? c_mul(p, p) : p);                     /* :94 / :119 (p**2 is p*p in flang) */
     }
     switch (m->timeType) {
     case 1: return c_div(c_exp(c_scale(p, -t1)), p);                                       /* :47-49 */
@@ -1085,7 +1116,10 @@ static int point_R(const ucf_params* P, const mdl* m, const double* j0z,
                 ser[j] = glarea[((size_t)j * nz + z) * np + i];
                 if (c_abs(ser[j]) > RC(0.0)) any = 1;
             }
-            infint[(size_t)z * np + i] = any ? wynn_R(nacc, ser, NULL) : c_make(RC(0.0), RC(0.0));
+            int wst = 0;
+            infint[(size_t)z * np + i] = any ? wynn_R(nacc, ser, &wst) : c_make(RC(0.0), RC(0.0));
+            if (!any) cnt_add(5, 1);
+            else if (wst >= 1 && wst <= 3) cnt_add(1 + wst, 1);
             totlap[(size_t)z * np + i] = c_add(finint[(size_t)z * np + i], infint[(size_t)z * np + i]);
         }
     /* driver.f90:217-230 */
@@ -1124,7 +1158,9 @@ int ucfo_point(const ucf_params* P, const ucf_derived* D, const double* j0z,
     R zr[UCF_MAX_NZ], hr[UCF_MAX_NZ], dr[UCF_MAX_NZ];
     if (nz > UCF_MAX_NZ) return -1;
     for (int k = 0; k < nz; k++) zr[k] = (R)zD[k];
+    g_count_on = 1;
     int rc = point_R(P, &m, j0z, (R)tD, (R)rD, sv, nz, zr, zLay, hr, dr, stage);
+    g_count_on = 0;
     for (int k = 0; k < nz; k++) { h[k] = (double)hr[k]; dh[k] = (double)dr[k]; }
     return rc;
 }

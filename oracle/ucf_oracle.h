@@ -77,6 +77,11 @@ int ucfo_point(const ucf_params* P, const ucf_derived* D, const double* j0z,
                double tD, double rD, int sv, int nz, const double* zD, const int* zLay,
                double* h, double* dh, ucfo_stage* stage);
 
+/* counters of the in-band rules taken by ucfo_point / ucfo_batch since the last reset, in the order of ucf_stats
+ * (include/ucf.h): nan_scrubbed, zero_vectors, wynn_truncated, wynn_sentinel, wynn_early_exit, wynn_all_zero */
+void ucfo_stats_reset(void);
+void ucfo_stats_get(long long* out6);
+
 /* many points, OpenMP over points (threads<=0: all cores); returns 0 */
 int ucfo_batch(const ucf_params* P, int npts, const double* tD, const double* rD, const int* sv,
                int nz, const double* zD, const int* zLay, double* h, double* dh, int threads);

@@ -73,3 +73,34 @@ def rel_err(x, ref, floor=1e-3):
     """|x-ref| / max(|ref|, floor)  (measure iii)"""
     x = np.asarray(x, float); ref = np.asarray(ref, float)
     return np.abs(x - ref) / np.maximum(np.abs(ref), floor)
+
+
+def e2e_gate_bounds(oracle, name, ir, factor=20.0):
+    """per-row bounds of the end-to-end gate (2) of tests/test_gpu_parity.py for radius `ir` of deck `name`:
+    max(1e-10, factor x noise), noise = the larger of the reference's build-to-build spread (running max over +-8
+    rows) and its error against the binary128 evaluation on the truth subsample.  Returns (ref rows, bound_h, bound_dh);
+    errors are relative with the floor max(|ref|, 1e-3) on the DIMENSIONAL (as printed) values."""
+    e2e = load_e2e(name)
+    tr = np.load(os.path.join(GOLD, f"truth_{name}.npz"))
+    dk, ts, P = load_deck(name)
+    D = oracle.nondim(P)
+    t = oracle.logspace(ts.min_log, ts.max_log, ts.n)
+    tD = t / D.Tc
+    sv = oracle.split_vector(list(dk.j0s), tD)
+    zz = oracle.linspace(dk.zBot, dk.zTop, 1 if dk.piezometer else dk.zOrd)
+    zD = zz / D.Lc
+    zl = oracle.zlay(D, zD)
+    rD = np.full_like(tD, float(e2e["radii"][ir]) / D.Lc)
+    idx = tr["idx"]
+    ho, dho = oracle.batch(P, tD[idx], rD[idx], sv[idx], zD, zl)
+    sc = 1.0 if dk.dimless else D.Hc
+    fl_raw = 1e-3 / sc
+    noise_t = (float(rel_err(ho, tr[f"h_r{ir}"], fl_raw).max()), float(rel_err(dho, tr[f"dh_r{ir}"], fl_raw).max()))
+    ref, alt = e2e[f"O2_r{ir}"], e2e[f"O3native_r{ir}"]
+    out = []
+    for col, nt_ in ((1, noise_t[0]), (2, noise_t[1])):
+        spread = rel_err(alt[:, col], ref[:, col], 1e-3)
+        k = 8
+        sp = np.array([spread[max(0, i - k): i + k + 1].max() for i in range(len(spread))])
+        out.append(np.maximum(1e-10, factor * np.maximum(sp, nt_)))
+    return ref, out[0], out[1]

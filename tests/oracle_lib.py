@@ -164,6 +164,16 @@ class Oracle:
             raise RuntimeError(f"oracle: unsupported model (rc={rc})")
         return (h, dh, bufs) if stages else (h, dh)
 
+    STAT_NAMES = ("nan_scrubbed", "zero_vectors", "wynn_truncated", "wynn_sentinel", "wynn_early_exit", "wynn_all_zero")
+
+    def batch_with_stats(self, P, tD, rD, sv, zD, zLay, threads=0):
+        """batch + the counts of the in-band rules it took (same counters as ucf_stats)"""
+        self.lib.ucfo_stats_reset()
+        h, dh = self.batch(P, tD, rD, sv, zD, zLay, threads)
+        out = (C.c_longlong * 6)()
+        self.lib.ucfo_stats_get(out)
+        return h, dh, dict(zip(self.STAT_NAMES, [int(v) for v in out]))
+
     def batch(self, P, tD, rD, sv, zD, zLay, threads=0):
         tD = np.ascontiguousarray(tD, np.float64)
         rD = np.ascontiguousarray(rD, np.float64)

@@ -8,42 +8,82 @@ import sys
 import numpy as np
 import pytest
 
-from golden_util import DECKS, rel_err
-from unconfined_amd.deck import Deck
+from golden_util import DECKS, e2e_gate_bounds, load_e2e, rel_err
+from unconfined_amd.deck import Deck, SpaceSpec, TimeSpec
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = os.path.join(ROOT, "oracle", "_ref", "O2", "unconfined")
+REF_ALT = os.path.join(ROOT, "oracle", "_ref", "O3native", "unconfined")
 
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name", ["neuman74_partpen", "c3_moench", "contour_neuman"])
-def test_cli_output_file(tmp_path, name):
+def _cli(tmp_path, name, mode="faithful"):
     dk = Deck.read(os.path.join(DECKS, f"{name}.in"))
     for fn in (f"{name}.in", dk.timeFileName if dk.timeseries else dk.spaceFileName):
         shutil.copy(os.path.join(DECKS, fn), tmp_path)
     env = dict(os.environ, PYTHONPATH=ROOT)
-    res = subprocess.run([sys.executable, "-m", "unconfined_amd", f"{name}.in", "--mode", "faithful", "--out", "ours.out"],
+    res = subprocess.run([sys.executable, "-m", "unconfined_amd", f"{name}.in", "--mode", mode, "--out", "ours.out"],
                          cwd=tmp_path, env=env, capture_output=True, text=True)
     assert res.returncode == 0, res.stderr[-2000:]
-    ours = [ln for ln in open(tmp_path / "ours.out").read().split("\n") if ln]
+    return dk, [ln for ln in open(tmp_path / "ours.out").read().split("\n") if ln]
+
+
+@pytest.mark.parametrize("name", ["neuman74_partpen", "c3_moench"])
+def test_cli_time_series_file(tmp_path, oracle, name):
+    dk, ours = _cli(tmp_path, name)
     if not os.path.exists(REF):
         pytest.skip("reference binary not shipped")
     subprocess.run([REF, f"{name}.in"], cwd=tmp_path, env=dict(os.environ, OMP_NUM_THREADS="8"), check=True, capture_output=True)
     ref = [ln for ln in open(tmp_path / dk.outFileName, errors="replace").read().split("\n") if ln]
     assert len(ours) == len(ref)
-    ncol = 3 if dk.timeseries else 4
-    first_r = None
-    for a, b in zip(ours, ref):
-        if b.startswith("#"):
-            assert a == b
-            continue
-        va, vb = [float(x) for x in a.split()], [float(x) for x in b.split()]
-        assert va[:ncol - 2] == vb[:ncol - 2]
-        if not dk.timeseries:
-            # the reference is only right for its first radius (quirk Q1: later radii reuse its abscissae)
-            first_r = vb[1] if first_r is None else first_r
-            if vb[1] != first_r:
-                continue
-        assert rel_err(np.array(va[-2]), np.array(vb[-2]), 1e-3) < 1e-8
-        assert rel_err(np.array(va[-1]), np.array(vb[-1]), 1e-3) < 1e-6
+    assert [a for a in ours if a.startswith("#")] == [b for b in ref if b.startswith("#")]
+    va = np.array([[float(x) for x in a.split()] for a in ours if not a.startswith("#")])
+    vb = np.array([[float(x) for x in b.split()] for b in ref if not b.startswith("#")])
+    assert np.array_equal(va[:, 0], vb[:, 0])
+    e2e = load_e2e(name)
+    ir = int(np.argmin(np.abs(e2e["radii"] - dk.rval)))
+    fix, bh, bd = e2e_gate_bounds(oracle, name, ir)          # the gate of tests/test_gpu_parity.py, per row
+    assert np.array_equal(fix, vb)                            # the binary run here writes what the fixture holds
+    assert (rel_err(va[:, 1], vb[:, 1], 1e-3) <= bh).all()
+    assert (rel_err(va[:, 2], vb[:, 2], 1e-3) <= bd).all()
+
+
+def test_cli_contour_file_every_radius(tmp_path):
+    """contour mode: header bytes and (z, r) columns against the reference's contour run; VALUES at every (r, z)
+    against one reference TIME-SERIES run per point -- the reference's own contour values are wrong for every radius
+    after the first (it keeps the first radius' tanh-sinh abscissae), its single-point runs are
+    not.  Gate: max(1e-10, 20 x the reference's -O2 / -O3-native spread at that point)."""
+    name = "contour_neuman"
+    dk, ours = _cli(tmp_path, name)
+    if not (os.path.exists(REF) and os.path.exists(REF_ALT)):
+        pytest.skip("reference binaries not shipped")
+    env = dict(os.environ, OMP_NUM_THREADS="8")
+    subprocess.run([REF, f"{name}.in"], cwd=tmp_path, env=env, check=True, capture_output=True)
+    ref = [ln for ln in open(tmp_path / dk.outFileName, errors="replace").read().split("\n") if ln]
+    assert len(ours) == len(ref)
+    assert [a for a in ours if a.startswith("#")] == [b for b in ref if b.startswith("#")]
+    va = np.array([[float(x) for x in a.split()] for a in ours if not a.startswith("#")])
+    vb = np.array([[float(x) for x in b.split()] for b in ref if not b.startswith("#")])
+    assert np.array_equal(va[:, :2], vb[:, :2])
+    TimeSpec(False, 0, 1, 1, times=[dk.tval]).write(tmp_path / "one_time.dat")
+    wrong_in_reference = 0
+    for row_ours, row_contour in zip(va, vb):
+        z, r = row_ours[0], row_ours[1]
+        d = dk.replace(timeseries=True, piezometer=True, rval=float(r), zTop=float(z), zBot=float(z), timeFileName="one_time.dat",
+                       outFileName="pt.out")
+        d.write(tmp_path / "pt.in")
+        vals = []
+        for exe in (REF, REF_ALT):
+            subprocess.run([exe, "pt.in"], cwd=tmp_path, env=env, check=True, capture_output=True)
+            rows = [ln for ln in open(tmp_path / "pt.out", errors="replace").read().split("\n") if ln and not ln.startswith("#")]
+            assert len(rows) == 1
+            vals.append([float(x) for x in rows[0].split()])
+        (t0, h0, d0), (_, h1, d1) = vals
+        assert t0 == dk.tval
+        bh = max(1e-10, 20.0 * float(rel_err(h1, h0, 1e-3)))
+        bd = max(1e-10, 20.0 * float(rel_err(d1, d0, 1e-3)))
+        assert rel_err(row_ours[2], h0, 1e-3) <= bh, (z, r, row_ours[2], h0)
+        assert rel_err(row_ours[3], d0, 1e-3) <= bd, (z, r, row_ours[3], d0)
+        wrong_in_reference += int(rel_err(row_contour[2], h0, 1e-3) > 1e-6)
+    assert wrong_in_reference > 0            # quirk Q1 is real: the reference's contour file disagrees with its own point runs

@@ -85,14 +85,16 @@ UCF_DEV cplx cinv_plain_(cplx z)
 // ------------------------------------------------------------------ time.f90:34-80
 UCF_DEV cplx lap_time(const ucf_dev_params& P, cplx p)
 {
-    if (P.timeType < 0) {                                                                        // :81-95
-        const int n = -P.timeType;
+    if (P.timeType < 0) {                                                                        // :81-95, :97-122
+        const bool linear = P.timeType <= -101;          // piecewise linear: slope increments, and p^2 below
+        const int n = linear ? -P.timeType - 100 : -P.timeType;
         cplx sum = cmake(0.0, 0.0);
         for (int k = 0; k < n; k++) {
             const cplx term = rscale(P.sched[n + k], cexp_(rscale(-P.sched[k], p)));
             sum = (k == 0) ? term : cadd(sum, term);
         }
-        return cdiv(csub(sum, rscale(P.sched[2 * n + 1], cexp_(rscale(-P.sched[2 * n], p)))), p);
+        const cplx num = csub(sum, rscale(P.sched[2 * n + 1], cexp_(rscale(-P.sched[2 * n], p))));
+        return cdiv(num, linear ? cmul(p, p) : p);                                               // :92-94 / :117-119
     }
     const double t1 = P.timePar[0], t2 = P.timePar[1];
     switch (P.timeType) {
@@ -611,7 +613,7 @@ UCF_DEV double dehoog_wave2(const cplx (&f)[2], int M, double alpha, double logt
     const int n2 = 2 * M;
     double mag = 0.0;
     cplx ff[2], q[2], e[2];
-    bool anynan = false;
+    bool nans[2];
 #pragma unroll
     for (int g = 0; g < 2; g++) {
         const int i = lane + 64 * g;
@@ -620,7 +622,7 @@ UCF_DEV double dehoog_wave2(const cplx (&f)[2], int M, double alpha, double logt
         if (d_isnan(m1)) m1 = 0.0;
         mag = fmax(mag, m1);
         const bool nanp = act && (d_isnan(f[g].re) || d_isnan(f[g].im));
-        anynan |= nanp;
+        nans[g] = nanp;
         ff[g] = (nanp || !act) ? cmake(act ? 0.0 : 1.0, 0.0) : f[g];
     }
     const double mx = wave_max(mag);
@@ -628,7 +630,7 @@ UCF_DEV double dehoog_wave2(const cplx (&f)[2], int M, double alpha, double logt
         if (st) stat_add(&st->zero_vectors, lane == 0);
         return 0.0;
     }
-    if (st) stat_add(&st->nan_scrubbed, anynan);
+    if (st) { stat_add(&st->nan_scrubbed, nans[0]); stat_add(&st->nan_scrubbed, nans[1]); }      // per sample
     const double gamma = alpha - logtol / (2.0 * tee);
     const cplx ff0 = bcast0(ff[0]);
     const cplx d0 = cdivr(ff0, 2.0);

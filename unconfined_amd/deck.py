@@ -196,7 +196,13 @@ class Deck:
         t = _toks(lines[3], 2, "rw,rc"); dk.rw, dk.rc = _fnum(t[0]), _fnum(t[1])
         dk.gammaSkin = _fnum(_toks(lines[4], 1, "gamma")[0])
         dk.timeType = _inum(_toks(lines[5], 1, "time behaviour")[0])
-        npar = 2 if dk.timeType > -1 else (2 * ((-dk.timeType) % 100) + 1)
+        # -n: n-step piecewise constant (n = 1..100); -(100+n): n-segment piecewise linear; 2n+1 parameters either way
+        # (the reference sizes the record with mod(type,100), driver_io.f90:124, which breaks for -100 and -200)
+        if dk.timeType > -1:
+            npar = 2
+        else:
+            nseg = -dk.timeType if dk.timeType >= -100 else -dk.timeType - 100
+            npar = 2 * nseg + 1
         t = _toks(lines[5], 1 + npar, "time behaviour parameters")
         dk.timePar = [_fnum(x) for x in t[1:]]
         dk.b = _fnum(_toks(lines[6], 1, "b")[0])
@@ -261,6 +267,32 @@ class Deck:
 
     def replace(self, **kw) -> "Deck":
         return dataclasses.replace(self, **kw)
+
+    def check_observation(self, t, r, z, space_computed: bool = True) -> None:
+        """the checks on where and when the solution is observed, on which the reference prints ERROR and stops
+        (driver_io.f90:355-394 time series, :443-449 listed times, :494-519 contour grids)"""
+        if self.timeseries:
+            if self.zTop < self.zBot:
+                raise DeckError(f"for screened observation wells top of monitoring well screen must be at or above bottom: "
+                                f"top={self.zTop} bot={self.zBot}")
+            if self.zTop > self.b or self.zBot < 0.0:
+                raise DeckError(f"top of monitoring well screen must be above bottom and both between 0 and b: "
+                                f"top={self.zTop} bot={self.zBot} b={self.b}")
+            if not self.piezometer and self.zOrd < 1:
+                raise DeckError(f"# of quadrature points at monitoring location must be > 0: {self.zOrd}")
+            if self.rwobs <= 0.0:
+                raise DeckError(f"monitoring well radius must be >0: {self.rwobs}")
+            if self.sF <= 0.0:
+                raise DeckError(f"monitoring well shape factor must be >0: {self.sF}")
+            if not self.rval > self.rw:
+                raise DeckError(f"r must be > rw: r={self.rval} rw={self.rw}")
+            if any(x < 0.0 for x in t):
+                raise DeckError("all times must be > 0")
+        else:
+            if any(x < 0.0 or x > self.b for x in z):
+                raise DeckError(f"z must be in range 0<=>b: zmin={min(z)} zmax={max(z)} b={self.b}")
+            if not space_computed and any(x < self.rw for x in r):        # (the reference checks listed radii only)
+                raise DeckError(f"r must be >= rw: rmin={min(r)} rw={self.rw}")
 
 
 def resolve(deck_path: str, name: str) -> str:

@@ -314,6 +314,7 @@ class DeckResult:
 def grids_from_deck(dk: Deck, deck_path: Optional[str] = None, ts: Optional[TimeSpec] = None,
                     sp: Optional[SpaceSpec] = None):
     """times, radii, depths as read_input builds them (driver_io.f90:385-523)"""
+    dk.check_observation([], [], [])                 # what can be said before any grid exists
     if dk.timeseries:
         if ts is None:
             ts = TimeSpec.read(resolve(deck_path or ".", dk.timeFileName))
@@ -329,6 +330,7 @@ def grids_from_deck(dk: Deck, deck_path: Optional[str] = None, ts: Optional[Time
             z = linspace(sp.min_z, sp.max_z, sp.n_z)
         else:
             r, z = _f64(sp.r), _f64(sp.z)
+    dk.check_observation(t, r, z, space_computed=(dk.timeseries or sp.compute))
     return t, r, z
 
 

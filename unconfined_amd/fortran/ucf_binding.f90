@@ -40,7 +40,8 @@ module ucf_binding
 
   public :: ucf_version, ucf_last_error, ucf_plan_create, ucf_plan_destroy, ucf_plan_update, ucf_plan_derived, &
        & ucf_plan_set_mode, ucf_logspace, ucf_linspace, ucf_zlay, ucf_split_vector, &
-       & ucf_drawdown_grid, ucf_drawdown_batch, ucf_screen_average, ucf_error_message
+       & ucf_drawdown_grid, ucf_drawdown_batch, ucf_screen_average, ucf_error_message, &
+       & ucf_nondimensionalise, ucf_device_count, ucf_plan_create_on, ucf_shard_rows, ucf_drawdown_grid_multi
 
   interface
      function ucf_version() bind(C, name='ucf_version') result(v)
@@ -143,6 +144,51 @@ module ucf_binding
        type(ucf_stats), intent(out) :: stats
        integer(c_int) :: rc
      end function ucf_drawdown_batch
+
+     ! read_input's checks and non-dimensionalisation (driver_io.f90:88-333,531-567); host arithmetic, no GPU
+     function ucf_nondimensionalise(P, D) bind(C, name='ucf_nondimensionalise') result(rc)
+       import :: c_int, ucf_params, ucf_derived
+       type(ucf_params), intent(in) :: P
+       type(ucf_derived), intent(out) :: D
+       integer(c_int) :: rc
+     end function ucf_nondimensionalise
+
+     function ucf_device_count(n) bind(C, name='ucf_device_count') result(rc)
+       import :: c_int
+       integer(c_int), intent(out) :: n
+       integer(c_int) :: rc
+     end function ucf_device_count
+
+     ! a plan bound to HIP device `device` (0-based)
+     function ucf_plan_create_on(P, device, plan) bind(C, name='ucf_plan_create_on') result(rc)
+       import :: c_int, c_ptr, ucf_params
+       type(ucf_params), intent(in) :: P
+       integer(c_int), value :: device
+       type(c_ptr), intent(out) :: plan
+       integer(c_int) :: rc
+     end function ucf_plan_create_on
+
+     ! rows [lo, hi) (0-based) of the nt-row sweep that shard `rank` of `world` owns
+     function ucf_shard_rows(nt, world, rank, lo, hi) bind(C, name='ucf_shard_rows') result(rc)
+       import :: c_int
+       integer(c_int), value :: nt, world, rank
+       integer(c_int), intent(out) :: lo, hi
+       integer(c_int) :: rc
+     end function ucf_shard_rows
+
+     ! the same loop nest on ngpu devices at once: plans(g) bound to device g, rows of the i loop (driver.f90:100) in
+     ! contiguous blocks, every device's block copied straight to its place in h, dh ([nz, nr, nt] in Fortran order)
+     function ucf_drawdown_grid_multi(plans, ngpu, nt, tD, sv, nr, rD, nz, zD, zLay, h, dh, stats) &
+          & bind(C, name='ucf_drawdown_grid_multi') result(rc)
+       import :: c_int, c_double, c_ptr, ucf_stats
+       type(c_ptr), intent(in) :: plans(*)
+       integer(c_int), value :: ngpu, nt, nr, nz
+       real(c_double), intent(in) :: tD(*), rD(*), zD(*)
+       integer(c_int), intent(in) :: sv(*), zLay(*)
+       real(c_double), intent(out) :: h(*), dh(*)
+       type(ucf_stats), intent(out) :: stats
+       integer(c_int) :: rc
+     end function ucf_drawdown_grid_multi
 
      function ucf_screen_average(npts, zOrd, h, havg) bind(C, name='ucf_screen_average') result(rc)
        import :: c_int, c_double

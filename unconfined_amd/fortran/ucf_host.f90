@@ -1,22 +1,30 @@
 ! ucf_host.f90 -- thin Fortran host: deck in, drawdown rows out, all numerics on the GPU.
 !
-!   ucf_host <deck> [faithful|fast]
+!   ucf_host <deck> [faithful|fast|header] [ngpu]          ("header": parameter echo only, needs no GPU)
 !
 ! Does what `./unconfined <deck>` does for a time-series or contour deck (18-line format of
 ! input-explanation.txt), with the serial/OpenMP loop nest of driver.f90:100-232 replaced by
-! ONE call through ISO_C_BINDING (ucf_drawdown_grid).  Rows use the reference's edit
-! descriptors (constants.f90:72-73: ES14.07E2 / ES24.15E4) so outputs are comparable line by
-! line; the header is a short '#' block of our own (the reference's is cosmetic).
+! ONE call through ISO_C_BINDING: ucf_drawdown_grid_multi, which cuts the rows of the i loop
+! (driver.f90:100) into contiguous blocks over `ngpu` MI355X (default: every visible device, at
+! most one per time row) and gathers the blocks into the result arrays.  The result file is the
+! reference's: same '#' parameter echo (ucf_output, driver_io.f90:668-845) and rows in the same
+! edit descriptors (constants.f90:72-73: ES14.07E2 / ES24.15E4), so outputs diff line by line.
+! UCF_HOST_ONE_DEVICE=1 (rehearsal on a one-GPU box): all plans on device 0.
 program ucf_host
   use, intrinsic :: iso_c_binding
   use ucf_binding
+  use ucf_output
   implicit none
 
   type(ucf_params) :: P
   type(ucf_derived) :: D
   type(ucf_stats) :: st
   type(c_ptr) :: plan
-  character(len=512) :: deckname, modearg, tfile, sfile, outname
+  type(c_ptr), allocatable :: plans(:)
+  type(run_shape) :: shape
+  integer(c_int) :: ngpu, ndev, g, ngpu_asked
+  logical :: header_only
+  character(len=512) :: deckname, modearg, gpuarg, onedev, tfile, sfile, outname
   character(len=8192) :: line
   character(len=64) :: tok(256)
   integer :: ntok, quiet, zOrd, ios, mode, i, k, m, u
@@ -33,6 +41,9 @@ program ucf_host
   call get_command_argument(2, modearg)
   mode = 0
   if (trim(modearg) == 'fast') mode = 1
+  call get_command_argument(3, gpuarg)
+  ngpu = 0
+  if (len_trim(gpuarg) > 0) read(gpuarg, *, iostat=ios) ngpu
 
   open(newunit=u, file=trim(deckname), status='old', action='read', iostat=ios)
   if (ios /= 0) call die('cannot open deck '//trim(deckname))
@@ -49,8 +60,10 @@ program ucf_host
   if (P%timeType > -1) then
      if (ntok < 3) call die('time behaviour needs two parameters')
      P%timePar(1) = num(tok(2)); P%timePar(2) = num(tok(3))
-  else                                   ! -n: 2n+1 schedule parameters (driver_io.f90:119-127)
-     k = 2*mod(-P%timeType, 100) + 1
+  else                                   ! -n / -(100+n): 2n+1 schedule parameters (driver_io.f90:119-127)
+     k = -P%timeType
+     if (k > 100) k = k - 100
+     k = 2*k + 1
      if (k > 2*UCF_MAX_SCHEDULE+1 .or. ntok < 1 + k) call die('pumping schedule: wrong number of parameters')
      do i = 1, k
         P%timeParExt(i) = num(tok(1+i))
@@ -81,10 +94,35 @@ program ucf_host
   close(u)
   P%pad0 = 0; P%pad1 = 0
 
-  rc = ucf_plan_create(P, plan)
-  if (rc /= UCF_OK) call die('ucf_plan_create: '//ucf_error_message())
+  rc = ucf_nondimensionalise(P, D)
+  if (rc /= UCF_OK) call die('bad deck: '//ucf_error_message())
+  header_only = (trim(modearg) == 'header')
+
+  ! one plan per GPU (the plans are replicas: same parameters, each bound to its device)
+  ndev = 0
+  ngpu_asked = ngpu
+  if (header_only) then
+     ngpu = 0
+     allocate(plans(0))
+  else
+  rc = ucf_device_count(ndev)
+  if (rc /= UCF_OK) call die('ucf_device_count: '//ucf_error_message())
+  if (ngpu <= 0) ngpu = ndev
+  call get_environment_variable('UCF_HOST_ONE_DEVICE', onedev)
+  if (ngpu > ndev .and. trim(onedev) /= '1') call die('more GPUs asked for than are visible')
+  allocate(plans(ngpu))
+  do g = 1, ngpu
+     if (trim(onedev) == '1') then
+        rc = ucf_plan_create_on(P, 0_c_int, plans(g))
+     else
+        rc = ucf_plan_create_on(P, g - 1, plans(g))
+     end if
+     if (rc /= UCF_OK) call die('ucf_plan_create_on: '//ucf_error_message())
+     rc = ucf_plan_set_mode(plans(g), int(mode, c_int))
+  end do
+  plan = plans(1)
   rc = ucf_plan_derived(plan, D)
-  rc = ucf_plan_set_mode(plan, int(mode, c_int))
+  end if
 
   ! ---- where and when (driver_io.f90:385-523)
   if (timeseries) then
@@ -104,6 +142,14 @@ program ucf_host
         end do
      end if
      close(u)
+     ! the checks of driver_io.f90:355-394,443-449 (the reference prints ERROR and stops)
+     if (zTop < zBot) call die('top of monitoring well screen must be at or above bottom')
+     if (zTop > P%b .or. zBot < 0.0_c_double) call die('top of monitoring well screen must be above bottom and both between 0 and b')
+     if (.not. piezometer .and. zOrd < 1) call die('# of quadrature points at monitoring location must be > 0')
+     if (P%rwobs <= 0.0_c_double) call die('monitoring well radius must be >0')
+     if (P%sF <= 0.0_c_double) call die('monitoring well shape factor must be >0')
+     if (.not. rval > P%rw) call die('r must be > rw')
+     if (any(t < 0.0_c_double)) call die('all times must be > 0')
      nr = 1
      allocate(r(1)); r(1) = rval
      if (piezometer) zOrd = 1
@@ -128,8 +174,20 @@ program ucf_host
         allocate(r(nr), z(nz))
         read(u,*) r(1:nr)
         read(u,*) z(1:nz)
+        if (any(r < P%rw)) call die('r must be >= rw')                                  ! driver_io.f90:505-507
      end if
      close(u)
+     if (any(z < 0.0_c_double) .or. any(z > P%b)) call die('z must be in range 0<=>b')    ! :494-497,516-519
+  end if
+
+  if (header_only) then
+     open(newunit=u, file=trim(outname), status='replace', action='write')
+     shape%dimless = dimless; shape%timeseries = timeseries; shape%piezometer = piezometer
+     shape%zOrd = zOrd; shape%nt = nt; shape%zTop = zTop; shape%zBot = zBot; shape%tval = tval
+     shape%r = r; shape%z = z
+     call echo_parameters(u, P, D, shape)
+     close(u)
+     stop
   end if
 
   allocate(tD(nt), rD(nr), zD(nz), sv(nt), zLay(nz), h(nz*nr*nt), dh(nz*nr*nt))
@@ -140,18 +198,21 @@ program ucf_host
   rc = ucf_split_vector(plan, nt, tD, sv)
 
   ! ---- the hot path: one call instead of the OpenMP loop nest
-  rc = ucf_drawdown_grid(plan, nt, tD, sv, nr, rD, nz, zD, zLay, h, dh, st)
-  if (rc /= UCF_OK) call die('ucf_drawdown_grid: '//ucf_error_message())
+  if (ngpu > nt) ngpu = nt
+  rc = ucf_drawdown_grid_multi(plans, ngpu, nt, tD, sv, nr, rD, nz, zD, zLay, h, dh, st)
+  if (rc /= UCF_OK) call die('ucf_drawdown_grid_multi: '//ucf_error_message())
 
   sc = D%Hc
   if (dimless) sc = 1.0_c_double
 
   open(newunit=u, file=trim(outname), status='replace', action='write')
-  write(u,'(A)') '# unconfined-mi355x (ucf_host): deck '//trim(deckname)
-  write(u,'(A,I0,A,I0,A,I0,A,I0)') '# model ', P%model, '  nt ', nt, '  nr ', nr, '  nz ', nz
-  write(u,'(A,3(1X,ES14.07E2))') '# Lc Tc Hc', D%Lc, D%Tc, D%Hc
-  write(u,'(A,6(1X,I0))') '# in-band rules fired (nan_scrubbed zero_vectors wynn_truncated '// &
-       & 'wynn_sentinel wynn_early_exit wynn_all_zero):', st%nan_scrubbed, st%zero_vectors, &
+  shape%dimless = dimless; shape%timeseries = timeseries; shape%piezometer = piezometer
+  shape%zOrd = zOrd; shape%nt = nt; shape%zTop = zTop; shape%zBot = zBot; shape%tval = tval
+  shape%r = r; shape%z = z
+  call echo_parameters(u, P, D, shape)
+  ! (what the reference's quiet > 0 progress lines would say goes to the terminal, not into the file)
+  write(*,'(A,I0,A,6(1X,I0))') 'ucf_host: ', ngpu, ' GPU(s); in-band rules fired (nan_scrubbed zero_vectors '// &
+       & 'wynn_truncated wynn_sentinel wynn_early_exit wynn_all_zero):', st%nan_scrubbed, st%zero_vectors, &
        & st%wynn_truncated, st%wynn_sentinel, st%wynn_early_exit, st%wynn_all_zero
   if (timeseries) then
      allocate(ha(nt), da(nt))
@@ -161,7 +222,6 @@ program ucf_host
      else
         ha = h(1:nt); da = dh(1:nt)
      end if
-     write(u,'(A)') '#      t              h                        dh/dlnt'
      do i = 1, nt
         if (dimless) then
            write(u,'(ES14.07E2,1X,2(ES24.15E4,1X))') tD(i), ha(i), da(i)
@@ -170,7 +230,6 @@ program ucf_host
         end if
      end do
   else
-     write(u,'(A)') '#      z              r              h                        dh/dlnt'
      do k = 1, nr
         do m = 1, nz
            i = m + nz*(k-1)
@@ -183,7 +242,9 @@ program ucf_host
      end do
   end if
   close(u)
-  call ucf_plan_destroy(plan)
+  do g = 1, size(plans)
+     call ucf_plan_destroy(plans(g))
+  end do
 
 contains
 

@@ -22,7 +22,7 @@ _ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
 
 EXPORTS = [
     "ucf_version", "ucf_last_error", "ucf_status_string",
-    "ucf_plan_create", "ucf_plan_destroy", "ucf_plan_update", "ucf_plan_derived", "ucf_plan_j0z", "ucf_plan_tanh_sinh",
+    "ucf_plan_create", "ucf_plan_create_on", "ucf_device_count", "ucf_plan_destroy", "ucf_plan_update", "ucf_plan_derived", "ucf_nondimensionalise", "ucf_plan_j0z", "ucf_plan_tanh_sinh",
     "ucf_plan_gauss_lobatto", "ucf_plan_set_mode", "ucf_plan_set_timing", "ucf_plan_kernel_ms", "ucf_plan_kernel_times",
     "ucf_plan_reserve", "ucf_plan_alloc_count", "ucf_build_id",
     "ucf_shard_rows", "ucf_drawdown_grid_shard_device", "ucf_drawdown_grid_multi",
@@ -70,9 +70,12 @@ def load() -> C.CDLL:
     lib.ucf_status_string.argtypes = [C.c_int]
     lib.ucf_plan_create.argtypes = [C.POINTER(UcfParams), C.POINTER(vp)]
     lib.ucf_plan_destroy.argtypes = [vp]
+    lib.ucf_plan_create_on.argtypes = [C.POINTER(UcfParams), C.c_int, C.POINTER(vp)]
+    lib.ucf_device_count.argtypes = [C.POINTER(C.c_int)]
     lib.ucf_plan_update.argtypes = [vp, C.POINTER(UcfParams)]
     lib.ucf_plan_destroy.restype = None
     lib.ucf_plan_derived.argtypes = [vp, C.POINTER(UcfDerived)]
+    lib.ucf_nondimensionalise.argtypes = [C.POINTER(UcfParams), C.POINTER(UcfDerived)]
     lib.ucf_plan_j0z.argtypes = [vp, C.c_int, _dp]
     lib.ucf_plan_tanh_sinh.argtypes = [vp, C.c_int, C.c_int, _dp, vp]
     lib.ucf_plan_gauss_lobatto.argtypes = [vp, C.c_int, _dp, _dp]
