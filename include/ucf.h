@@ -44,7 +44,8 @@ extern "C" {
 #define UCF_MAX_MOENCH 16      /* max number of Moench alphas (driver_io.f90:142-151) */
 #define UCF_MAX_NZ 32          /* depths per LAUNCH; calls with more depths are walked in chunks by the library */
 #define UCF_MAX_SCHEDULE 100    /* steps of a piecewise-constant pumping schedule (time.f90:81-95) */
-#define UCF_MAX_LAP_M 63       /* 2M+1 <= 128: the wave-cooperative de Hoog holds at most two samples per lane */
+#define UCF_MAX_LAP_M 127      /* 2M+1 <= 256: the wave-cooperative de Hoog holds up to four samples per lane (the reference takes
+                                  any M >= 2, driver_io.f90:306-309; its QD table is numerically void long before M = 127) */
 
 typedef enum ucf_status {
     UCF_OK = 0,

@@ -68,7 +68,8 @@ def test_input_validation_mirrors_reference_stops(so):
         (dict(model=7), -1), (dict(l=1.0, d=2.0), -2), (dict(b=-1.0), -3), (dict(kappa=0.0), -3),
         (dict(model=6, MNtype=2, order=2), -4), (dict(beta=-1.0), -5), (dict(model=3, MoenchM=0), -6),
         (dict(M=1), -7), (dict(k=4, R=4), -8), (dict(R=0), -8), (dict(nacc=0), -9),
-        (dict(model=6, MNtype=0), -10), (dict(M=64), -10), (dict(timeType=-101), -10),
+        (dict(model=6, MNtype=0), -10), (dict(M=128), -10), (dict(timeType=-201), -10), (dict(timeType=0), -10),
+        (dict(timeType=-102, timePar=[1.0, 1.0, 3.0, 1.0, 2.0]), -11),
     ]
     for kw, want in cases:
         P = params_from_deck(base.replace(**kw))

@@ -388,9 +388,9 @@ def test_edge_cases(engine, oracle, oracle_quad):
     assert np.array_equal(np.isnan(hx), np.isnan(hox))
     assert rel_err(hx[:, 0], hox[:, 0], 1e-6).max() < 1e-7      # the depth inside the aquifer; the other one is
     # ill-conditioned beyond comparison (the reference's own values reach 1e15 there)
-    # Laplace sample counts around the wave width: 2M+1 = 63 (one per lane), 65 and 127 (two per lane)
+    # Laplace sample counts around the wave width: 2M+1 = 63 (one per lane), 65 and 127 (two per lane), 129 and 255 (four)
     tDm = np.array([0.05, 1.0, 40.0]); rDm = np.array([0.5, 0.5, 0.5]); svm = np.ones(3, np.int32)
-    for M in (31, 32, 63):
+    for M in (31, 32, 63, 64, 127):
         Pm = type(P).from_buffer_copy(P); Pm.M = M
         pm = engine.Plan(Pm)
         h, dh = pm.drawdown(tDm, rDm, svm, zD[:2], zl[:2])
@@ -398,12 +398,19 @@ def test_edge_cases(engine, oracle, oracle_quad):
         if M < 63:
             assert rel_err(h, ho, 1e-6).max() < 1e-7, M
         else:
-            # 127 Laplace samples: the QD table amplifies rounding so much that only the comparison with
+            # >= 127 Laplace samples: the QD table amplifies rounding so much that only the comparison with
             # exact arithmetic is meaningful -- the device must be as close to it as the binary64 oracle is
             ht, dht = oracle_quad.batch(Pm, tDm, rDm, svm, zD[:2], zl[:2], threads=8)
             assert rel_err(h, ht, 1e-6).max() <= max(1e-9, 10.0 * rel_err(ho, ht, 1e-6).max()), (M, rel_err(h, ht, 1e-6).max(), rel_err(ho, ht, 1e-6).max())
         hg, dg = pm.drawdown_grid(tDm, svm, rDm[:1], zD[:2], zl[:2])
         assert np.array_equal(hg[:, 0, :], h), M            # grid (lane = time) and per-point entries: same bits
+        # the de Hoog stage hook at this M against the oracle's (binary128 where the binary64 table is void)
+        rng = np.random.default_rng(M)
+        fp = np.stack([1.0 / (1.0 + np.arange(2 * M + 1)) ** 1.5 * (1 + 0.1 * rng.standard_normal(2 * M + 1)),
+                       -0.3 / (1.0 + np.arange(2 * M + 1)) * (1 + 0.1 * rng.standard_normal(2 * M + 1))], axis=1)
+        got = engine.dehoog(M, 1e-8, 1e-9, 1.3, 2.6, fp[None])[0]
+        r64 = oracle.dehoog(M, 1e-8, 1e-9, 1.3, 2.6, fp); r128 = oracle_quad.dehoog(M, 1e-8, 1e-9, 1.3, 2.6, fp)
+        assert abs(got - r128) <= max(1e-12 * abs(r128), 10.0 * abs(r64 - r128)), (M, got, r64, r128)
 
 
 _PIPE_SCRIPT = r"""

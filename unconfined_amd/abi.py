@@ -6,7 +6,7 @@ import ctypes as C
 
 UCF_MAX_MOENCH = 16
 UCF_MAX_NZ = 32
-UCF_MAX_LAP_M = 63
+UCF_MAX_LAP_M = 127
 UCF_MAX_SCHEDULE = 100
 
 

@@ -597,25 +597,31 @@ UCF_DEV double dehoog_cf_lane(const lds_c* dcol, int pitch, int M, double alpha,
     return exp(gamma * t) / tee * cdiv(A2M, B2M).re;                                            // :129
 }
 
-// Same algorithm for 64 < 2M+1 <= 128: element i = lane + 64 g lives in register set g of its lane
-// (M up to 63).  Used by dehoog_points_kernel only; elementwise identical to dehoog_wave.
-UCF_DEV void shift_down_128(const cplx (&in)[2], cplx (&out)[2], int lane)
+// Same algorithm for 2M+1 > 64: element i = lane + 64 g lives in register set g of its lane, G = 2 sets for
+// 2M+1 <= 128, G = 4 for 2M+1 <= 256 (M up to 127).  Used by dehoog_points_kernel and the big-M branch of
+// dehoog_tiles_kernel; elementwise identical to dehoog_wave.
+template <int G>
+UCF_DEV void shift_down_sets(const cplx (&in)[G], cplx (&out)[G], int lane)
 {
-    const cplx a = shfl_down1(in[0]), b = shfl_down1(in[1]);
-    const cplx b0 = bcast0(in[1]);
-    out[0] = (lane == 63) ? b0 : a;
-    out[1] = b;
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+        const cplx a = shfl_down1(in[g]);
+        // lane 63 of set g takes element 64 (g + 1) = lane 0 of the next set; the last set keeps its own
+        const cplx nx = (g + 1 < G) ? bcast0(in[g + 1 < G ? g + 1 : g]) : a;
+        out[g] = (lane == 63 && g + 1 < G) ? nx : a;
+    }
 }
 
-UCF_DEV double dehoog_wave2(const cplx (&f)[2], int M, double alpha, double logtol, double t, double tee, int lane,
-                            ucf_stats* st)
+template <int G>
+UCF_DEV double dehoog_sets(const cplx (&f)[G], int M, double alpha, double logtol, double t, double tee, int lane,
+                           ucf_stats* st)
 {
     const int n2 = 2 * M;
     double mag = 0.0;
-    cplx ff[2], q[2], e[2];
-    bool nans[2];
+    cplx ff[G], q[G], e[G];
+    bool nans[G];
 #pragma unroll
-    for (int g = 0; g < 2; g++) {
+    for (int g = 0; g < G; g++) {
         const int i = lane + 64 * g;
         const bool act = i <= n2;
         double m1 = act ? cabs_(f[g]) : 0.0;
@@ -630,14 +636,17 @@ UCF_DEV double dehoog_wave2(const cplx (&f)[2], int M, double alpha, double logt
         if (st) stat_add(&st->zero_vectors, lane == 0);
         return 0.0;
     }
-    if (st) { stat_add(&st->nan_scrubbed, nans[0]); stat_add(&st->nan_scrubbed, nans[1]); }      // per sample
+    if (st) {
+#pragma unroll
+        for (int g = 0; g < G; g++) stat_add(&st->nan_scrubbed, nans[g]);      // per sample
+    }
     const double gamma = alpha - logtol / (2.0 * tee);
     const cplx ff0 = bcast0(ff[0]);
     const cplx d0 = cdivr(ff0, 2.0);
-    cplx fn[2];
-    shift_down_128(ff, fn, lane);
+    cplx fn[G];
+    shift_down_sets<G>(ff, fn, lane);
 #pragma unroll
-    for (int g = 0; g < 2; g++) {
+    for (int g = 0; g < G; g++) {
         const int i = lane + 64 * g;
         q[g] = (i == 0) ? cdiv(fn[g], d0) : cdiv(fn[g], ff[g]);
         if (i > n2 - 1) q[g] = cmake(1.0, 0.0);
@@ -647,11 +656,11 @@ UCF_DEV double dehoog_wave2(const cplx (&f)[2], int M, double alpha, double logt
     const cplx z = cexp_(cdivr(cscale(cscale(cmake(0.0, 1.0), UCF_PI), t), tee));
     cplx dlast_q = cmake(0.0, 0.0), dlast_e = cmake(0.0, 0.0);
     for (int r = 1; r <= M; r++) {
-        cplx qn[2], en[2], enew[2];
-        shift_down_128(q, qn, lane);
-        shift_down_128(e, en, lane);
+        cplx qn[G], en[G], enew[G];
+        shift_down_sets<G>(q, qn, lane);
+        shift_down_sets<G>(e, en, lane);
 #pragma unroll
-        for (int g = 0; g < 2; g++) {
+        for (int g = 0; g < G; g++) {
             const int i = lane + 64 * g;
             enew[g] = cadd(csub(qn[g], q[g]), en[g]);
             if (i > 2 * (M - r)) enew[g] = cmake(1.0, 0.0);
@@ -667,10 +676,10 @@ UCF_DEV double dehoog_wave2(const cplx (&f)[2], int M, double alpha, double logt
             cplx An = cadd(Am1, cmul(cmul(de, Am2), z));
             cplx Bn = cadd(Bm1, cmul(cmul(de, Bm2), z));
             Am2 = Am1; Am1 = An; Bm2 = Bm1; Bm1 = Bn;
-            cplx enn[2];
-            shift_down_128(enew, enn, lane);
+            cplx enn[G];
+            shift_down_sets<G>(enew, enn, lane);
 #pragma unroll
-            for (int g = 0; g < 2; g++) {
+            for (int g = 0; g < G; g++) {
                 const int i = lane + 64 * g;
                 q[g] = cdiv(cmul(qn[g], enn[g]), enew[g]);
                 if (i > 2 * (M - r - 1) + 1) q[g] = cmake(1.0, 0.0);
@@ -687,6 +696,23 @@ UCF_DEV double dehoog_wave2(const cplx (&f)[2], int M, double alpha, double logt
     const cplx A2M = cadd(Am1, cmul(rem, Am2));
     const cplx B2M = cadd(Bm1, cmul(rem, Bm2));
     return exp(gamma * t) / tee * cdiv(A2M, B2M).re;
+}
+
+// h and dh of one vector of 2M+1 > 64 transform samples read by `load(i)`, p_i = sigma + i pi/tee
+template <int G, class LOAD>
+UCF_DEV void dehoog_big(LOAD load, int np, int M, double alpha, double logtol, double sigma, double tD, double tee, int lane,
+                        ucf_stats* st, double* hval, double* dval)
+{
+    cplx tl[G], tp[G];
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+        const int i = lane + 64 * g;
+        tl[g] = cmake(0.0, 0.0);
+        if (i < np) tl[g] = load(i);
+        tp[g] = cmul(tl[g], cmake(sigma, UCF_PI * i / tee));
+    }
+    *hval = dehoog_sets<G>(tl, M, alpha, logtol, tD, tee, lane, st);
+    *dval = dehoog_sets<G>(tp, M, alpha, logtol, tD, tee, lane, st) * tD;
 }
 
 // ------------------------------------------------------------- integration.f90:125-189
@@ -1455,16 +1481,10 @@ dehoog_tiles_kernel(const ucf_dev_params P, int nt, int nr, int ir0, int nrc, co
                     const double tD = tDv[it];
                     const double tee = 2.0 * tD;
                     const double sigma = P.alpha - P.logtol / (2.0 * tee);
-                    cplx tl[2], tp[2];
-#pragma unroll
-                    for (int g = 0; g < 2; g++) {
-                        const int i = lane + 64 * g;
-                        tl[g] = cmake(0.0, 0.0);
-                        if (i < np) { const lds_c v = lds[i * pitch + tt]; tl[g] = cmake(v.x, v.y); }
-                        tp[g] = cmul(tl[g], cmake(sigma, UCF_PI * i / tee));
-                    }
-                    const double hval = dehoog_wave2(tl, P.M, P.alpha, P.logtol, tD, tee, lane, st);
-                    const double dval = dehoog_wave2(tp, P.M, P.alpha, P.logtol, tD, tee, lane, st) * tD;
+                    double hval, dval;
+                    auto ld = [&](int i) { const lds_c v = lds[i * pitch + tt]; return cmake(v.x, v.y); };
+                    if (np <= 2 * UCF_WAVE) dehoog_big<2>(ld, np, P.M, P.alpha, P.logtol, sigma, tD, tee, lane, st, &hval, &dval);
+                    else dehoog_big<4>(ld, np, P.M, P.alpha, P.logtol, sigma, tD, tee, lane, st, &hval, &dval);
                     if (lane == 0) {
                         const size_t o = ((size_t)it * nr + ir0 + irl) * P.nz_out + P.z_off + z;
                         hout[o] = hval;
@@ -1513,16 +1533,9 @@ dehoog_points_kernel(const ucf_dev_params P, long long npc, int flat, int per_po
                 hval = dehoog_wave(tl, P.M, P.alpha, P.logtol, tD, tee, lane, st);
                 dval = dehoog_wave(cmul(tl, p), P.M, P.alpha, P.logtol, tD, tee, lane, st) * tD;
             } else {
-                cplx tl[2], tp[2];
-#pragma unroll
-                for (int g = 0; g < 2; g++) {
-                    const int i = lane + 64 * g;
-                    tl[g] = cmake(0.0, 0.0);
-                    if (i < P.np) { const double2 v = src[i]; tl[g] = cmake(v.x, v.y); }
-                    tp[g] = cmul(tl[g], cmake(sigma, UCF_PI * i / tee));
-                }
-                hval = dehoog_wave2(tl, P.M, P.alpha, P.logtol, tD, tee, lane, st);
-                dval = dehoog_wave2(tp, P.M, P.alpha, P.logtol, tD, tee, lane, st) * tD;
+                auto ld = [&](int i) { const double2 v = src[i]; return cmake(v.x, v.y); };
+                if (P.np <= 2 * UCF_WAVE) dehoog_big<2>(ld, P.np, P.M, P.alpha, P.logtol, sigma, tD, tee, lane, st, &hval, &dval);
+                else dehoog_big<4>(ld, P.np, P.M, P.alpha, P.logtol, sigma, tD, tee, lane, st, &hval, &dval);
             }
             if (lane == 0) {
                 hout[obase * P.nz_out + P.z_off + z] = hval;
@@ -1599,8 +1612,17 @@ dehoog_kernel(int n, int M, double alpha, double logtol, const double* __restric
     const int i = blockIdx.x;
     if (i >= n) return;
     const int np = 2 * M + 1;
-    cplx f = (lane < np) ? cmake(fp[((size_t)i * np + lane) * 2], fp[((size_t)i * np + lane) * 2 + 1]) : cmake(0.0, 0.0);
-    const double v = dehoog_wave(f, M, alpha, logtol, t[i], tee[i], lane, nullptr);
+    auto ld = [&](int k) { return (k < np) ? cmake(fp[((size_t)i * np + k) * 2], fp[((size_t)i * np + k) * 2 + 1]) : cmake(0.0, 0.0); };
+    double v;
+    if (np <= UCF_WAVE) {
+        v = dehoog_wave(ld(lane), M, alpha, logtol, t[i], tee[i], lane, nullptr);
+    } else if (np <= 2 * UCF_WAVE) {
+        const cplx f2[2] = {ld(lane), ld(lane + 64)};
+        v = dehoog_sets<2>(f2, M, alpha, logtol, t[i], tee[i], lane, nullptr);
+    } else {
+        const cplx f4[4] = {ld(lane), ld(lane + 64), ld(lane + 128), ld(lane + 192)};
+        v = dehoog_sets<4>(f4, M, alpha, logtol, t[i], tee[i], lane, nullptr);
+    }
     if (lane == 0) ft[i] = v;
 }
 
