@@ -324,11 +324,11 @@ def worker(args):
 
         def collect():
             try:
-                for name, ms in plan.kernel_times():        # waits for the previous step's kernels only
+                for name, ms, cnt in plan.kernel_times():   # waits for the previous step's kernels only
                     if name not in per_kernel:
                         per_kernel[name] = []
                         order.append(name)
-                    per_kernel[name].append(ms)
+                    per_kernel[name].append((ms, cnt))
             except Exception:
                 pass
         torch.cuda.synchronize()
@@ -348,7 +348,10 @@ def worker(args):
             tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = float(tt.item())
-        return elapsed, [(n, float(np.mean(per_kernel[n]))) for n in order]
+        # per kernel: average duration of ONE launch and launches per step (a step that walks the radii in chunks
+        # launches every kernel once per chunk)
+        return elapsed, [(n, float(np.sum([m for m, _ in per_kernel[n]]) / max(1, np.sum([c for _, c in per_kernel[n]]))),
+                          int(round(np.mean([c for _, c in per_kernel[n]])))) for n in order]
 
     if args.scaling == "weak":
         alloc_weak()
@@ -403,13 +406,14 @@ def worker(args):
         fma_peak = None
     build_id = engine.build_id()
     prof, prof_src = load_profile(build_id, args.workload, args.mode)
-    dom = max(kernels, key=lambda kv: kv[1]) if kernels else ("all kernels of a step", elapsed / args.steps * 1e3)
+    dom = max(kernels, key=lambda kv: kv[1] * kv[2]) if kernels else ("all kernels of a step", elapsed / args.steps * 1e3, 1)
+    pts_kernel_launch = pts_launch / dom[2]                                # points one launch of the dominant kernel processes
     rows = []
-    for name, ms in kernels:
-        r = {"name": name, "ms": ms}
+    for name, ms, cnt in kernels:
+        r = {"name": name, "ms": ms, "launches_per_step": cnt}
         pk = (prof or {}).get("kernels", {}).get(name)
         if pk:
-            scale = pts_launch / float(prof["points_per_launch"])          # counters are proportional to the points of a launch
+            scale = (pts_launch / cnt) / float(prof["points_per_launch"])  # counters are proportional to the points of a launch
             if pk.get("fp64_flop_per_launch") is not None:
                 fl = pk["fp64_flop_per_launch"] * scale
                 r.update({"fp64_flop_per_launch": fl, "executed_TFLOPs": fl / (ms * 1e-3) * 1e-12,
@@ -422,8 +426,8 @@ def worker(args):
                     r[k] = pk[k]
         rows.append(r)
     drow = next((r for r in rows if r["name"] == dom[0]), {})
-    alg_bytes = (20 + 16 * nz) * pts_launch
-    conv_tf = flop_per_pt * pts_launch / (dom[1] * 1e-3) * 1e-12
+    alg_bytes = (20 + 16 * nz) * pts_kernel_launch
+    conv_tf = flop_per_pt * pts_kernel_launch / (dom[1] * 1e-3) * 1e-12
     line = {
         "metric": "(t,r) drawdown points/sec, Neuman-1974 1024x256 sweep; max |rel err| vs CPU ref",
         "value": value, "unit": "points/s", "n_gpus": n_ranks, "steps": args.steps, "warmup": args.warmup,
@@ -439,7 +443,8 @@ def worker(args):
                    "build_id": build_id, "results_finite_and_gather_consistent": ok},
         "roofline": {"bound": "fp64_valu", "achieved": drow.get("executed_TFLOPs"), "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s",
                      "frac": drow.get("frac"), "traffic": drow.get("hbm_bytes_per_launch"),
-                     "kernel": dom[0], "kernel_ms": dom[1], "step_kernels_ms": float(sum(ms for _, ms in kernels)) if kernels else None,
+                     "kernel": dom[0], "kernel_ms": dom[1], "kernel_launches_per_step": dom[2], "points_per_kernel_launch": pts_kernel_launch,
+                     "step_kernels_ms": float(sum(ms * c for _, ms, c in kernels)) if kernels else None,
                      "definition": "achieved = fp64 flop EXECUTED by the dominant kernel per launch (64 lanes x (2 FMA + ADD + MUL + TRANS) wave "
                                    "instructions, rocprofv3 --pmc) / its average launch duration over the timed steps (HIP events on the launch stream)",
                      "executed_flop_source": prof_src,

@@ -163,12 +163,13 @@ int ucf_plan_gauss_lobatto(const ucf_plan* plan, int n, double* x, double* w);
  *                 1 = fast (same algorithm, FMA contraction + shared subexpressions). */
 int ucf_plan_set_mode(ucf_plan* plan, int mode);
 
-/* measurement: when enabled, every kernel of a following single-chunk grid call (lane = time layout) is bracketed by
- * HIP events on the call's stream.  ucf_plan_kernel_times waits for the brackets of the last such call and returns, in
- * launch order, duration [ms] and name of each kernel (names as rocprofv3 prints them, without the argument list);
- * ucf_plan_kernel_ms returns the longest one (the dominant kernel of the path). */
+/* measurement: when enabled, every kernel of a following grid call in the lane = time layout is bracketed by HIP events
+ * on the call's stream.  ucf_plan_kernel_times waits for the brackets of the last such call and returns one row per
+ * kernel in order of first launch: total duration [ms], number of launches (a call that walks the radii in chunks
+ * launches every kernel once per chunk; may be NULL) and name (as rocprofv3 prints it, without "void " and the
+ * argument list); ucf_plan_kernel_ms returns the per-launch duration of the kernel with the largest total. */
 int ucf_plan_set_timing(ucf_plan* plan, int enable);
-int ucf_plan_kernel_times(ucf_plan* plan, int cap, double* ms, const char** names, int* n);
+int ucf_plan_kernel_times(ucf_plan* plan, int cap, double* ms, int* launches, const char** names, int* n);
 int ucf_plan_kernel_ms(ucf_plan* plan, double* ms, const char** kernel_name);
 
 /* Size the workspaces of `stream` (hipStream_t as void*, NULL = default stream) for calls to come -- a grid of nt x nr

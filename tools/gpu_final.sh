@@ -1,16 +1,39 @@
 #!/bin/bash
-# end-of-round evidence: full GPU tests, default bench, kernel trace, traffic and SQ counters of the final build
+# The evidence set of a build, one pass (tools/collect_profiles.py <tag> copies the summaries into profiles/):
+#   for every BASELINE workload at FULL size on one GPU -- C2 1024x256 (headline), C2pp, C3 2048x512, C4 4096x1024,
+#   C5 1024x256 -- the five driver-reproducible commands
+#     rocprofv3 --kernel-trace --stats            -- python3 bench.py --steps 3 --warmup 1 --no-cpu --workload W
+#     rocprofv3 --pmc <SQ issue counters>         -- python3 bench.py --steps 1 --warmup 1 --no-cpu --workload W
+#     rocprofv3 --pmc <fp64 instruction counters> -- (same)
+#     rocprofv3 --pmc FETCH_SIZE                  -- (same)       (separate passes: the TCC counters do not fit one)
+#     rocprofv3 --pmc WRITE_SIZE                  -- (same)
+#   then the GPU tests, the default bench line (with the CPU baseline) and the faithful-flavour line.
+# WORKLOADS="c2 c4" restricts the first part; SKIP_TESTS=1 skips the second.
 set -o pipefail
 mkdir -p gpurun_out
 R=$GRAFT_REPO_ROOT
-timeout -k 10 900 python -m pytest tests -m gpu -q --no-header -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1; rc=$?; echo "[pytest] rc=$rc $(tail -1 gpurun_out/pytest_gpu.log)"; [ $rc -ge 124 ] && exit $rc
-timeout -k 10 600 python bench.py > gpurun_out/bench_default.log 2>&1; rc=$?; echo "[bench] rc=$rc"; [ $rc -ge 124 ] && exit $rc
-timeout -k 10 600 python bench.py --mode faithful --no-cpu > gpurun_out/bench_faithful.log 2>&1; rc=$?; echo "[bench faithful] rc=$rc"; [ $rc -ge 124 ] && exit $rc
 cd /tmp; export TMPDIR=/tmp
-rm -rf $R/gpurun_out/final_*
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final_trace -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu > $R/gpurun_out/final_trace.log 2>&1; echo "[trace] rc=$?"
-for C in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 400 rocprofv3 --pmc $C --output-format csv -d $R/gpurun_out/final_$C -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu > $R/gpurun_out/final_$C.log 2>&1; rc=$?; echo "[$C] rc=$rc"; [ $rc -ge 124 ] && exit $rc
+run() { # name, rocprof args..., then bench args after --
+  local name=$1; shift
+  rm -rf $R/gpurun_out/$name
+  timeout -k 10 500 rocprofv3 "$@" > $R/gpurun_out/$name.log 2>&1; local rc=$?
+  echo "[$name] rc=$rc"; [ $rc -ge 124 ] && exit $rc; return 0
+}
+for W in ${WORKLOADS:-c2 c2pp c3 c4 c5}; do
+  B="python3 $R/bench.py --warmup 1 --no-cpu --workload $W"
+  run fin_${W}_trace --kernel-trace --stats --output-format csv -d $R/gpurun_out/fin_${W}_trace -- $B --steps 3
+  run fin_${W}_sq --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/fin_${W}_sq -- $B --steps 1
+  run fin_${W}_f64 --pmc SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_LDS SQ_INSTS_SMEM GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/fin_${W}_f64 -- $B --steps 1
+  run fin_${W}_FETCH_SIZE --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/fin_${W}_FETCH_SIZE -- $B --steps 1
+  run fin_${W}_WRITE_SIZE --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/fin_${W}_WRITE_SIZE -- $B --steps 1
 done
-timeout -k 10 400 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/final_sq -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu > $R/gpurun_out/final_sq.log 2>&1; rc=$?; echo "[sq] rc=$rc"; [ $rc -ge 124 ] && exit $rc
-timeout -k 10 400 rocprofv3 --pmc SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_LDS SQ_INSTS_SMEM GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/final_f64 -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu > $R/gpurun_out/final_f64.log 2>&1; echo "[f64] rc=$?"
+cd $R
+# the counters of THIS build become profiles/pmc_r02.json on the box, so that the bench lines below carry their roofline
+python3 tools/collect_profiles.py ${TAG:-r02} > gpurun_out/collect.log 2>&1; cp profiles/pmc_r02.json gpurun_out/pmc_r02.json
+[ -n "$SKIP_TESTS" ] && exit 0
+timeout -k 10 1000 python -m pytest tests -m gpu -q --no-header -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1; rc=$?; echo "[pytest] rc=$rc $(tail -1 gpurun_out/pytest_gpu.log)"; [ $rc -ge 124 ] && exit $rc
+timeout -k 10 600 python bench.py > gpurun_out/bench_default.log 2> gpurun_out/bench_default.err; rc=$?; echo "[bench] rc=$rc"; [ $rc -ge 124 ] && exit $rc
+timeout -k 10 600 python bench.py --mode faithful --no-cpu > gpurun_out/bench_faithful.log 2> gpurun_out/bench_faithful.err; rc=$?; echo "[bench faithful] rc=$rc"
+for W in c2pp c3 c4 c5; do
+  timeout -k 10 600 python bench.py --no-cpu --workload $W --steps 3 > gpurun_out/bench_$W.log 2> gpurun_out/bench_$W.err; echo "[bench $W] rc=$?"
+done

@@ -18,6 +18,7 @@
 
 #include "ucf_math.h"
 #include "ucf_plan.h"
+#include <cstdlib>
 
 namespace UCF_NS {
 
@@ -1209,8 +1210,10 @@ point_kernel(const ucf_dev_params P0, int npts, int per_point, int nr, int nsv, 
 #endif
 // WAVES per SIMD the register budget is cut for: as many as the LDS footprint admits (6 for nz = 1 at R = 4,
 // fully penetrating; 5; else 4)
+// UCF_IWPB waves per workgroup: they share nothing but the sin/cos table of sincos_tab_ in LDS (4 KB, copied once from
+// the plan's tables; one barrier, before the work loop); every wave keeps walking its own work items.
 template <int FAMILY, int LAYOUT, int WAVES, bool MULTI, bool FOLD, bool LAY3>
-__global__ void __launch_bounds__(UCF_WAVE, WAVES)
+__global__ void __launch_bounds__(UCF_WAVE * UCF_IWPB, WAVES)
 integrate_kernel(const ucf_dev_params P0, int npts, int per_point, int nr, int nsv, int svmin,
                  const double* __restrict__ tDv, const double* __restrict__ rDv, const int* __restrict__ svv,
                  const double2* __restrict__ tab, int nt, int ir0, double2* __restrict__ state, int* __restrict__ ndone,
@@ -1221,12 +1224,20 @@ integrate_kernel(const ucf_dev_params P0, int npts, int per_point, int nr, int n
     const ucf_dev_params& P = P0;
     UCF_K1_ASSUME      // tools/: specialise a probe build to one plan shape to read its inner loop
 #endif
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & (UCF_WAVE - 1), wv = threadIdx.x / UCF_WAVE;
     const int nz = P0.nz, R = P0.R, nacc = P0.nacc, N = P0.N, ngl = P0.ngl;
     const int nabs = N + nacc * ngl;
-    lds_c* accTS = lds;                                     // [R][nz]  level sums
-    lds_c* accCur = lds + (size_t)R * nz * UCF_WAVE;        // [nz]     area of the J0 interval being integrated
-    for (int pt = blockIdx.x; pt < npts; pt += gridDim.x) {
+    // LDS: [256] sin/cos table | per wave: [R][nz] level sums, [nz] area of the J0 interval being integrated
+    {
+        const double2* __restrict__ gt = (const double2*)P0.sc_tab;
+        for (int k = threadIdx.x; k < UCF_SC_ENTRIES; k += UCF_WAVE * UCF_IWPB) lds[k] = gt[k];
+    }
+    __syncthreads();
+    const lds_c* sct = lds;
+    lds_c* const wlds = lds + UCF_SC_ENTRIES + (size_t)wv * (R + 1) * nz * UCF_WAVE;
+    lds_c* accTS = wlds;                                    // [R][nz]  level sums
+    lds_c* accCur = wlds + (size_t)R * nz * UCF_WAVE;       // [nz]     area of the J0 interval being integrated
+    for (int pt = blockIdx.x * UCF_IWPB + wv; pt < npts; pt += gridDim.x * UCF_IWPB) {
         const work_item W = decode_item<LAYOUT>(P0, pt, lane, per_point, nr, nt, ir0);
         const ucf_dev_params& P = item_params<MULTI>(P0, Pv, (LAYOUT == 3 ? W.plan * ppp : W.pidx) + pbase, ppp);
         bool need_lay1 = false, need_lay3 = false, need_lay12 = false;
@@ -1243,8 +1254,9 @@ integrate_kernel(const ucf_dev_params P0, int npts, int per_point, int nr, int n
         const lane_consts LC = make_lane_consts(P, p, lt);
         double2* __restrict__ sti = state + (size_t)pt * state_slots(P0) * UCF_WAVE;
         double2* __restrict__ areas = sti + (size_t)(R + 1) * nz * UCF_WAVE;
-        for (int s = 0; s < (R + 1) * nz; s++) lds_st(lds, s, lane, cmake(0.0, 0.0));
+        for (int s = 0; s < (R + 1) * nz; s++) lds_st(wlds, s, lane, cmake(0.0, 0.0));
         fast_common F;
+        F.sct = sct;
 
         // abscissae increase monotonically (tanh-sinh on [0,arg], then the J0 intervals), so does Re(eta):
         // the fast evaluation is valid for a leading run of abscissae; point_kernel finishes the rest.
@@ -1299,7 +1311,7 @@ integrate_kernel(const ucf_dev_params P0, int npts, int per_point, int nr, int n
         // (the running area only matters to point_kernel, i.e. when the item is unfinished)
         const int nslots = (n < nabs) ? (R + 1) * nz : R * nz;
         for (int s = 0; s < nslots; s++) {
-            const cplx v = cmul(lds_ld(lds, s, lane), lt);
+            const cplx v = cmul(lds_ld(wlds, s, lane), lt);
             sti[(size_t)s * UCF_WAVE + lane] = make_double2(v.re, v.im);
         }
         if (lane == 0) {
@@ -1421,7 +1433,9 @@ finish_kernel(const ucf_dev_params P, int npts, int per_point, int nr, int nsv, 
 // For 2M+1 <= 64 the rhombus runs per vector (h and dh of each time) and leaves the continued-fraction
 // coefficients in LDS (h's in the column the input came from, dh's in a second tile); then 2 x UCF_DH_TILE lanes
 // each finish one vector.  The recurrence used to be uniform work repeated by all 64 lanes for every vector.
+#ifndef UCF_DH_TILE
 #define UCF_DH_TILE 8
+#endif
 #if UCF_TU_HAS(1) || UCF_TU_HAS(3)
 template <int TU>          // (a template only so that two translation units may hold it)
 __global__ void __launch_bounds__(UCF_WAVE)
@@ -1569,6 +1583,12 @@ samples_kernel(const ucf_dev_params P, int n_a, const double* __restrict__ av, d
     bool fast = false;
 #if UCF_FAST
     fast_common F;
+    {   // sin/cos table of the fast evaluators (the kernel's dynamic LDS holds it)
+        const double2* __restrict__ gt = (const double2*)P.sc_tab;
+        for (int k = threadIdx.x; k < UCF_SC_ENTRIES; k += UCF_WAVE) lds[k] = gt[k];
+        __syncthreads();
+        F.sct = lds;
+    }
     if (FAMILY == 1 || FAMILY == 2 || FAMILY == 4) {
         const lane_consts LC = make_lane_consts(P, p, lt);
         fast = __all(fast_prepare<FAMILY>(P, LC, a, need_lay1, F));
@@ -1784,14 +1804,17 @@ static int launch_transform_(const ucf_dev_params& dp, int nwork, int per_point,
     }
 #if UCF_FAST
     if (kind == 1) {
-        const size_t ilds = (size_t)(dp.R + 1) * dp.nz * UCF_WAVE * sizeof(lds_c);
+        // per workgroup: the sin/cos table + UCF_IWPB waves' accumulators; wlds = the footprint one wave accounts for
+        const size_t wlds = (size_t)(dp.R + 1) * dp.nz * UCF_WAVE * sizeof(lds_c) + UCF_SC_ENTRIES * sizeof(lds_c) / UCF_IWPB;
+        const size_t ilds = wlds * UCF_IWPB;
+        const dim3 igrid((unsigned)((nwork + UCF_IWPB - 1) / UCF_IWPB)), iblock(UCF_WAVE * UCF_IWPB);
 #define UCF_LAUNCH_I3(F, W, FO, L3)                                                                            \
     do {                                                                                                       \
         if (ilds > 64 * 1024)                                                                                  \
             (void)hipFuncSetAttribute((const void*)integrate_kernel<F, LAYOUT, W, MULTI, FO, L3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ilds); \
         std::snprintf(kname, sizeof(kname), UCF_STR(UCF_NS) "::integrate_kernel<%d, %d, %d, %s, %s, %s>", F, LAYOUT, W, MULTI ? "true" : "false", FO ? "true" : "false", L3 ? "true" : "false"); \
         ucf_tm_mark(tm, kname, s);                                                                             \
-        hipLaunchKernelGGL((integrate_kernel<F, LAYOUT, W, MULTI, FO, L3>), dim3((unsigned)nwork), block, ilds, s, dp, nwork, per_point, nr, nsv, svmin, \
+        hipLaunchKernelGGL((integrate_kernel<F, LAYOUT, W, MULTI, FO, L3>), igrid, iblock, ilds, s, dp, nwork, per_point, nr, nsv, svmin, \
                            d_tD, d_rD, d_sv, (const double2*)d_tab, nt, ir0, (double2*)d_state, d_ndone, d_todo, d_params, ppp, pbase); \
     } while (0)
         // a depth above the screen top anywhere in the call (in any plan of a parameter batch)?
@@ -1802,7 +1825,7 @@ static int launch_transform_(const ucf_dev_params& dp, int nwork, int per_point,
         if (lay3) UCF_LAUNCH_I3(F, W, false, true);                                                            \
         else UCF_LAUNCH_I3(F, W, false, false);                                                                \
     } while (0)
-        const bool w5 = ilds * 20 <= 160 * 1024;
+        const bool w5 = wlds * 20 <= 160 * 1024;
         // fully penetrating pumping well (every plan of a parameter batch must be): the screen terms are compiled out
         const bool fold = dp.fold_dD && dp.fold_lD1 && !MULTI;
         switch (fam) {
@@ -1810,7 +1833,10 @@ static int launch_transform_(const ucf_dev_params& dp, int nwork, int per_point,
         case 2:
             if (fold) {
                 // register budget by the waves the LDS footprint admits per SIMD (measured on C2: 51.6 / 50.3 ms at 5 / 6)
-                if (ilds * 24 <= 160 * 1024) UCF_LAUNCH_FOLD(2, 6);
+                static const int force_w = [] { const char* e = std::getenv("UCF_FOLD_WAVES_RT"); return e ? std::atoi(e) : 0; }();   // diagnostic
+                if (force_w == 4) UCF_LAUNCH_FOLD(2, 4);
+                else if (force_w == 5) UCF_LAUNCH_FOLD(2, 5);
+                else if (wlds * 24 <= 160 * 1024) UCF_LAUNCH_FOLD(2, 6);
                 else if (w5) UCF_LAUNCH_FOLD(2, UCF_FOLD_WAVES);
                 else UCF_LAUNCH_FOLD(2, 4);
             }
@@ -2017,6 +2043,7 @@ int launch_samples(const ucf_dev_params& dp, int n_a, const double* d_a, double 
     if (fam < 0) return UCF_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     size_t lds = (fam == 4 && !UCF_FAST) ? 2 * (size_t)dp.order * UCF_WAVE * sizeof(lds_c) : 16;
+    if (UCF_FAST) lds = UCF_SC_ENTRIES * sizeof(lds_c);
     dim3 grid(n_a), block(UCF_WAVE);
 #define UCF_LAUNCH(F)                                                                                          \
     do {                                                                                                       \

@@ -235,6 +235,40 @@ UCF_DEV void sincos_medium_(double x, double* sn, double* cs)
     *sn = (q & 2) ? -s_sel : s_sel;
     *cs = ((q + 1) & 2) ? -c_sel : c_sel;
 }
+// sin and cos together from a table in LDS, |x| < 1e6 (the caller's business): x = k h + y, h = 2 pi / UCF_SC_N,
+// |y| <= h/2 = 0.0123, (sin, cos)(k h) from the table (one ds_read_b128 per lane: LDS work, not VALU work), short
+// polynomials in y and the angle-addition formulas in the form S + (C sin y + S (cos y - 1)).  ~20 VALU instructions
+// against ~55 of sincos_medium_ (no quadrant selects, degree 7 / 6 instead of 13 / 14).
+//   * k = rint(x / h) by the magic-number addition (the integer is left in the low mantissa bits: no conversion);
+//   * h = H1 + H2 with H1 = pio2_1 / 64 (33 significant bits): x - k H1 is EXACT in one fma for |x| < 2^21 (the
+//     difference has < 53 significant bits), the second fma rounds once; what is left of h is 1e-28 k: nothing;
+//   * the table holds the correctly rounded values with exact symmetry (sin(k h) = 0 and 1 where it is), so that the
+//     results keep their relative accuracy next to the zeros of sin and cos: 0 + (1 * sin y + 0).
+// Error < 1.5 ulp (table entry 0.5, correction 0.5 ulp of a term <= 0.0123, final addition 0.5).
+#define UCF_SC_N 256
+UCF_DEV void sincos_tab_(double x, const double2* __restrict__ tab, double* sn, double* cs)
+{
+    const int salt = __builtin_amdgcn_readfirstlane(__double2hiint(x));
+#define K(c) UCF_KHERE(c, salt)
+    const double MAGIC = 6755399441055744.0;                                   // 1.5 * 2^52
+    const double t = fmak(x, K(4.07436654315252059568e+01), MAGIC);            // x * (128/pi) + magic
+    const double fn = t - MAGIC;
+    const int k = __double2loint(t) & (UCF_SC_N - 1);
+    const double r = __builtin_fma(-fn, 2.45436926052207127214e-02, x);        // pio2_1 / 64: exact
+    const double y = __builtin_fma(-fn, 9.49546954141592538956e-13, r);        // pio2_1t / 64
+    const double2 T = tab[k];                                                  // (sin, cos)(k pi / 128)
+    const double z = y * y;
+    // sin y - y = y z (s3 + z (s5 + z s7));  cos y - 1 = z (c2 + z (c4 + z c6))      (Taylor: |y| <= 0.0123 leaves
+    // relative 2e-21 in sin, absolute 1e-20 in cos)
+    const double ps = fmak(z, fmak(z, K(-1.98412698412698412698e-04), K(8.33333333333333333333e-03)), K(-1.66666666666666666667e-01));
+    const double pc = fmak(z, fmak(z, K(-1.38888888888888888889e-03), K(4.16666666666666666667e-02)), K(-0.5));
+#undef K
+    const double sy = __builtin_fma(y * z, ps, y);
+    const double cm1 = z * pc;
+    *sn = T.x + __builtin_fma(T.x, cm1, T.y * sy);
+    *cs = T.y + __builtin_fma(T.y, cm1, -(T.x * sy));
+}
+
 UCF_DEV void sincos_(double x, double* sn, double* cs)
 {
     if (__builtin_expect(!(fabs(x) < 1.0e6), 0)) {     // also NaN/Inf

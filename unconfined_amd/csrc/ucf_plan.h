@@ -43,11 +43,14 @@ struct ucf_dev_params {
     const double* j0z;     // [nj0z]
     const double* fd_e;    // [order]  exp(-beta1*(j-1)*h)
     const double* sched;   // timeType = -n: [n] start times | [n] rate increments | final time | sum of increments
+    const double* sc_tab;  // [UCF_SC_N = 256] x (sin, cos)(k pi / 128): copied into LDS by the fast flavour's kernels (sincos_tab_)
 };
+#define UCF_SC_ENTRIES 256
+#define UCF_IWPB 4             /* waves per workgroup of integrate_kernel: they share the sin/cos table in LDS */
 
-// HIP events around the kernels of the last single-chunk grid call issued through a workspace (measurement only):
+// HIP events around the kernels of the last lane = time grid call issued through a workspace (measurement only):
 // bracket i = ev[2i] .. ev[2i+1] around the kernel called name[i].
-#define UCF_MAX_TIMED 8
+#define UCF_MAX_TIMED 96          /* brackets per call: kernels of a launch sequence x chunks of radii */
 struct ucf_timers {
     void* ev[2 * UCF_MAX_TIMED];     // hipEvent_t, created on first use
     char name[UCF_MAX_TIMED][96];
@@ -98,6 +101,7 @@ struct ucf_workspace {
     bool dry = false;              // ucf_plan_reserve: size the buffers, launch nothing
     ucf_timers tm = {};
     int tm_valid = 0;
+    const char* tm_names[UCF_MAX_TIMED] = {};
 };
 
 struct ucf_plan {
@@ -110,7 +114,7 @@ struct ucf_plan {
     int device = 0;
     double* d_tables = nullptr;    // one allocation holding all tables
     size_t tables_bytes = 0;
-    size_t o_tsx = 0, o_tsw = 0, o_glx = 0, o_glw = 0, o_j0z = 0, o_fde = 0, o_sched = 0;     // offsets (doubles) of the tables in it
+    size_t o_tsx = 0, o_tsw = 0, o_glx = 0, o_glw = 0, o_j0z = 0, o_fde = 0, o_sched = 0, o_sct = 0;     // offsets (doubles) of the tables in it
     // host copies (for the accessor API)
     double* h_j0z = nullptr;
     double* h_ts_x = nullptr;

@@ -81,13 +81,15 @@ class Plan:
         return ms.value, (name.value or b"").decode()
 
     def kernel_times(self):
-        """[(kernel name, ms), ...] of every kernel of the last timed single-chunk grid call, in launch order"""
-        cap = 8
+        """[(kernel name, total ms, launches), ...] of the kernels of the last timed lane = time grid call, in order of
+        first launch (a call that walks the radii in chunks launches every kernel once per chunk)"""
+        cap = 16
         ms = (C.c_double * cap)()
+        cnt = (C.c_int * cap)()
         names = (C.c_char_p * cap)()
         n = C.c_int(0)
-        _libmod.check(self._lib.ucf_plan_kernel_times(self._h, cap, ms, names, C.byref(n)))
-        return [((names[i] or b"").decode(), ms[i]) for i in range(n.value)]
+        _libmod.check(self._lib.ucf_plan_kernel_times(self._h, cap, ms, cnt, names, C.byref(n)))
+        return [((names[i] or b"").decode(), ms[i], cnt[i]) for i in range(n.value)]
 
     def reserve(self, nt: int = 0, nr: int = 0, npts: int = 0, nz: int = 1, stream: int = 0):
         """size the workspaces of `stream` so that later *_device calls of these sizes allocate nothing"""

@@ -15,7 +15,9 @@ import numpy as np
 from .abi import UcfDerived, UcfParams, UcfStats
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libucf.so")
+# UCF_LIB_PATH: an experimental build of the SAME library (tools/ubench/build_variant.sh) for A/B timing; the product
+# path is unconfined_amd/libucf.so and nothing else is ever loaded without that variable
+LIB_PATH = os.environ.get("UCF_LIB_PATH") or os.path.join(HERE, "libucf.so")
 
 _dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
 _ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
@@ -82,7 +84,7 @@ def load() -> C.CDLL:
     lib.ucf_plan_set_mode.argtypes = [vp, C.c_int]
     lib.ucf_plan_set_timing.argtypes = [vp, C.c_int]
     lib.ucf_plan_kernel_ms.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_char_p)]
-    lib.ucf_plan_kernel_times.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_char_p), C.POINTER(C.c_int)]
+    lib.ucf_plan_kernel_times.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_char_p), C.POINTER(C.c_int)]
     lib.ucf_plan_reserve.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     lib.ucf_plan_alloc_count.argtypes = [vp]
     lib.ucf_plan_alloc_count.restype = C.c_longlong
