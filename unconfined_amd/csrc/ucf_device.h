@@ -290,6 +290,50 @@ UCF_DEV cplx hantush_z(const ucf_dev_params& P, const sample_common& S, double z
     return cdivr(cmul(udp, S.th), P.bD);                                                        // :200
 }
 
+#if UCF_FAST
+// 1 / B_2 of the finite-difference elimination (laplace_hankel_solutions.f90:501-509 with utility.f90:96-135 run from the
+// bottom node up; only x(1) is wanted, :521-523).  B_i = b_i - K / B_{i+1} is a Moebius map per node; with
+// B_{i+1} = N_{i+1} / N_{i+2} it becomes the three-term recurrence N_i = b_i N_{i+1} - K N_{i+2} (N_{n+1} = 1, N_n = b_n):
+// products only and ONE complex reciprocal at the end instead of one per node (8 instead of 14 instructions per node).
+// Scaled by c >= |b_i| per lane so that nothing over- or underflows (beta_i = b_i / c has modulus <= 1, K / c^2 <= 1/4);
+// the recurrence runs in the direction in which its dominant solution grows, i.e. stably.
+// b_i = bmid - B1 e_i (i < n), b_n = b_i + invhsq - b3h  (:501-502).
+UCF_DEV cplx fd_inverse_B2(const ucf_dev_params& P, cplx B1, double bmid, double invhsq, double b3h, double K)
+{
+    const int n = P.order;
+    const double emax = fmax(P.fd_e[0], P.fd_e[n - 1]);
+    const double ic = fast_rcp(fabs(bmid) + fabs(invhsq - b3h) + (fabs(B1.re) + fabs(B1.im)) * emax);      // 1 / c
+    const double bmc = bmid * ic, k2 = -(K * ic) * ic;
+    const cplx B1c = cmake(-(B1.re * ic), -(B1.im * ic));
+    cplx N2 = cmake(1.0, 0.0);                                                                       // N_{n+1}
+    cplx N1 = cmake(__builtin_fma(B1c.re, P.fd_e[n - 1], __builtin_fma(invhsq - b3h, ic, bmc)), B1c.im * P.fd_e[n - 1]);   // N_n = b_n / c
+    // one node: N_i = beta_i N_{i+1} + k2 N_{i+2}, beta_i = b_i / c = (bmc + B1c.re e_i, B1c.im e_i)          (:501)
+    auto node = [&](double e, cplx Na, cplx Nb) {
+        const double br = __builtin_fma(B1c.re, e, bmc), bi = B1c.im * e;
+        return cmake(__builtin_fma(br, Na.re, __builtin_fma(-bi, Na.im, k2 * Nb.re)),
+                     __builtin_fma(br, Na.im, __builtin_fma(bi, Na.re, k2 * Nb.im)));
+    };
+    // four nodes per trip: their four table entries are adjacent (one scalar load, one wait for it instead of four) and
+    // the three-term recurrence rotates through its registers without copies
+    int i = n - 1;
+    for (; i >= 5; i -= 4) {
+        const double e0 = P.fd_e[i - 1], e1 = P.fd_e[i - 2], e2 = P.fd_e[i - 3], e3 = P.fd_e[i - 4];
+        const cplx Na = node(e0, N1, N2);
+        const cplx Nb = node(e1, Na, N1);
+        N2 = node(e2, Nb, Na);
+        N1 = node(e3, N2, Nb);
+    }
+    for (; i >= 2; i--) {
+        const cplx N0 = node(P.fd_e[i - 1], N1, N2);
+        N2 = N1;
+        N1 = N0;
+    }
+    // B_2 = c N_2 / N_3  ->  1 / B_2 = N_3 / (c N_2) = N_3 conj(N_2) / (c |N_2|^2)
+    const double r = fast_rcp(N1.re * N1.re + N1.im * N1.im) * ic;
+    return cmake((N2.re * N1.re + N2.im * N1.im) * r, (N2.im * N1.re - N2.re * N1.im) * r);
+}
+#endif
+
 template <int FAMILY>   // 0 Theis, 1 Hantush, 2 water-table (models 3,4,5), 3 MN-Malama, 4 MN-FD, 5 Hantush+storage
 UCF_DEV void sample_prepare(const ucf_dev_params& P, double a, cplx p, bool need_lay1, sample_common& S,
                             lds_c* fdbuf, int lane, cplx lane_aux)
@@ -387,12 +431,7 @@ UCF_DEV void sample_prepare(const ucf_dev_params& P, double a, cplx p, bool need
         // exact arithmetic gives the same x(1) as the forward Thomas sweep of utility.f90:96-135)
         (void)fdbuf; (void)lane;
         const double K = csup * invhsq;
-        cplx Bn = csubr(caddr(rsub(b3h - 2.0 * invhsq, caddr(cscale(B1, P.fd_e[n - 1]), B2)), invhsq), b3h);   // b(n), :501-502
-        for (int i = n - 1; i >= 2; i--) {
-            const cplx bi = rsub(b3h - 2.0 * invhsq, caddr(cscale(B1, P.fd_e[i - 1]), B2));
-            Bn = csub(bi, rscale(K, cinv_plain_(Bn)));
-        }
-        const cplx iB2 = cinv_plain_(Bn);                               // 1/B_2
+        const cplx iB2 = fd_inverse_B2(P, B1, b3h - 2.0 * invhsq - B2, invhsq, b3h, K);     // 1/B_2
         const cplx B1p = csub(b1, cmul(rscale(csup, a2v), iB2));        // B_1 = b_1 - c_1 a_2 / B_2
         const cplx v1p = csub(v1, cmul(rscale(csup, iB2), v2));         // v'_1 = v_1 - (c_1/B_2) v_2
         cplx x = cdiv(v1p, B1p);
@@ -1433,12 +1472,17 @@ finish_kernel(const ucf_dev_params P, int npts, int per_point, int nr, int nsv, 
 // For 2M+1 <= 64 the rhombus runs per vector (h and dh of each time) and leaves the continued-fraction
 // coefficients in LDS (h's in the column the input came from, dh's in a second tile); then 2 x UCF_DH_TILE lanes
 // each finish one vector.  The recurrence used to be uniform work repeated by all 64 lanes for every vector.
+// tile of 4 times and a register budget of 4 waves per SIMD (measured on C2: 2.44 ms at 8 / 2, 2.06 ms at 4 / 4: the
+// rhombus is a dependent chain per vector, resident waves are what hides it)
 #ifndef UCF_DH_TILE
-#define UCF_DH_TILE 8
+#define UCF_DH_TILE 4
 #endif
 #if UCF_TU_HAS(1) || UCF_TU_HAS(3)
+#ifndef UCF_DH_WAVES
+#define UCF_DH_WAVES 4
+#endif
 template <int TU>          // (a template only so that two translation units may hold it)
-__global__ void __launch_bounds__(UCF_WAVE)
+__global__ void __launch_bounds__(UCF_WAVE, UCF_DH_WAVES)
 dehoog_tiles_kernel(const ucf_dev_params P, int nt, int nr, int ir0, int nrc, const double* __restrict__ tDv,
                     const double2* __restrict__ totlap, double* __restrict__ hout, double* __restrict__ dhout,
                     ucf_stats* st)

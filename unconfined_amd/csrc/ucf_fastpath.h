@@ -289,13 +289,8 @@ UCF_DEV void fast_common_terms(const ucf_dev_params& P, const lane_consts& L, do
         const cplx cc = cmake((b3h - invhsq - B2) - B1.re * P.fd_e[0], -(B1.im * P.fd_e[0]));   // :495,498
         const cplx eoh = cscale(S.eta, 1.0 / h);
         const cplx b1 = csub(cmul(cc, S.che), cmul(eoh, S.she));                                // :499-500
-        cplx Bn = cmake((bmid + invhsq - b3h) - B1.re * P.fd_e[n - 1], -(B1.im * P.fd_e[n - 1]));   // :501-502
-        for (int i = n - 1; i >= 2; i--) {
-            const double e = P.fd_e[i - 1];
-            const double r = K * fast_rcp(Bn.re * Bn.re + Bn.im * Bn.im);
-            Bn = cmake(__builtin_fma(-B1.re, e, bmid) - Bn.re * r, __builtin_fma(-B1.im, e, Bn.im * r));
-        }
-        const cplx iB2 = cinv_plain(Bn);
+        (void)n;
+        const cplx iB2 = fd_inverse_B2(P, B1, bmid, invhsq, b3h, K);                             // :501-502 (ucf_device.h)
         const cplx a2v = cscale(S.che, invhsq);                                                 // :508-509
         const cplx B1p = csub(b1, cmul(rscale(csup, a2v), iB2));
         const cplx iB1p = cinv_scaled(B1p);
