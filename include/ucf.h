@@ -279,6 +279,10 @@ int ucf_extraptozero(int n, int R, const double* x /*[R]*/, const double* y_re_i
  * k_re_im[n][2][2] = (K0, K1), ierr[n] as cbesk's IERR */
 int ucf_bessel_k01(int n, const double* z_re_im, double* k_re_im, int* ierr);
 
+/* the (sin, cos)(k pi / 128), k = 0..255, table that every plan uploads for the fast flavour's evaluators (host code, no
+ * GPU needed; tab[256][2]) */
+int ucf_sincos_table(double* tab);
+
 /* ---- measurement helper: sustained fp64 FMA rate of the device ---- */
 int ucf_fp64_fma_peak(double* tflops);
 

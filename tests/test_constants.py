@@ -16,7 +16,7 @@ def test_exp_polynomial_matches_its_generator():
     gen = [float(m) for m in re.findall(r"^s\d+ = ([0-9.e+-]+)$", out, flags=re.M)]
     assert len(gen) == 10
     src = open(os.path.join(ROOT, "unconfined_amd", "csrc", "ucf_fastpath.h")).read()
-    body = src[src.index("UCF_DEV double exp_pos(double x)"):src.index("UCF_DEV fprim prim(double x, double y)")]
+    body = src[src.index("UCF_DEV double exp_pos(double x)"):src.index("UCF_DEV fprim prim(double x, double y")]
     lits = [float(m) for m in re.findall(r"K\(([0-9.e+-]+)\)", body)]
     assert lits == gen[::-1]                                   # s9 ... s0 in Horner order
 
@@ -33,3 +33,35 @@ def test_cody_waite_constants():
     assert abs(Decimal(head) + Decimal(tail) - half_pi) < Decimal("1e-26")
     m = head.hex()                       # 33 significant bits: the low 20 bits of the 52-bit mantissa are zero
     assert int(m.split(".")[1].split("p")[0], 16) & ((1 << 20) - 1) == 0
+
+
+def test_sincos_table_reduction_constants_and_entries():
+    """sincos_tab_ (ucf_math.h): h = pi/128 = H1 + H2 with H1 = pio2_1 / 64 (a 33-bit head, so that x - k H1 is exact in one
+    fma), k = rint(x * 128/pi); the 256-entry table the plan uploads holds the correctly rounded (sin, cos)(k h) with exact
+    symmetry (zeros and ones exact: relative accuracy next to the zeros of sin and cos)"""
+    from decimal import Decimal, getcontext
+    import ctypes as C
+    import numpy as np
+    getcontext().prec = 60
+    src = open(os.path.join(ROOT, "unconfined_amd", "csrc", "ucf_math.h")).read()
+    body = src[src.index("UCF_DEV void sincos_tab_("):src.index("UCF_DEV void sincos_(double x, double* sn, double* cs)")]
+    h1 = float(re.search(r"__builtin_fma\(-fn, ([0-9.e+-]+), x\)", body).group(1))
+    h2 = float(re.search(r"__builtin_fma\(-fn, ([0-9.e+-]+), r\)", body).group(1))
+    inv = float(re.search(r"fmak\(x, K\(([0-9.e+-]+)\), MAGIC\)", body).group(1))
+    pi = Decimal("3.14159265358979323846264338327950288419716939937510582")
+    assert abs(Decimal(h1) + Decimal(h2) - pi / 128) < Decimal("1e-28")
+    assert h1 == 1.57079632673412561417e+00 / 64 and h2 == 6.07710050650619224932e-11 / 64
+    assert int(h1.hex().split(".")[1].split("p")[0], 16) & ((1 << 20) - 1) == 0        # 33 significant bits
+    assert abs(Decimal(inv) - 128 / pi) < Decimal("1e-14")
+    from unconfined_amd import lib
+    so = lib.load()
+    tab = np.zeros((256, 2))
+    assert so.ucf_sincos_table(tab.ctypes.data_as(C.POINTER(C.c_double))) == 0
+    k = np.arange(256)
+    ang = k.astype(np.longdouble) * (np.longdouble("3.14159265358979323846264338327950288") / 128)
+    assert np.array_equal(tab[:, 0], np.sin(ang).astype(np.float64) * (k % 128 != 0))     # sin(k pi) exactly 0
+    want_c = np.cos(ang).astype(np.float64) * (k % 128 != 64)
+    assert np.array_equal(tab[:, 1], want_c)
+    assert np.array_equal(tab[:128, 0], -tab[128:, 0]) and np.array_equal(tab[:128, 1], -tab[128:, 1])   # half-turn
+    assert np.array_equal(tab[64:128, 0], tab[:64, 1]) and np.array_equal(tab[64:128, 1], -tab[:64, 0])    # quarter-turn
+    assert np.array_equal(tab[1:64, 0], tab[63:0:-1, 1])                                                   # sin(t) = cos(pi/2 - t)
