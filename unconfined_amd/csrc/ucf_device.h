@@ -269,6 +269,7 @@ struct sample_common {
     cplx hs_pre;    // Hantush+storage: uDf/bD                             (:268,299)
     bool small_eta; // Re(eta) < MAXEXP                                   (:84)
     bool fd_use;    // |sigma1| > tiny                                    (:521)
+    bool clean3;    // fast flavour, resumed items: depths above the screen top take the cancellation-free form (lay3_udp_scaled)
 };
 
 // laplace_hankel_solutions.f90:133-202 for one depth; `lay` = layer of this depth
@@ -332,6 +333,36 @@ UCF_DEV cplx fd_inverse_B2(const ucf_dev_params& P, cplx B1, double bmid, double
     const double r = fast_rcp(N1.re * N1.re + N1.im * N1.im) * ic;
     return cmake((N2.re * N1.re + N2.im * N1.im) * r, (N2.im * N1.re - N2.re * N1.im) * r);
 }
+#endif
+
+#if UCF_FAST
+// g1 - g2 of the Hantush factor at a depth ABOVE THE SCREEN TOP (layer 3, laplace_hankel_solutions.f90:175-180,196) for
+// any eta, in decaying exponentials.  The reference subtracts two terms of size e^{eta c}/2, c = zD - dD1, that agree to
+// e^{-2 eta c}: its value carries rounding noise u e^{+eta c} which overtakes the value itself at eta c = 18 and keeps
+// growing.  With cosh A sinh B = [sinh(A+B) - sinh(A-B)]/2 the large parts cancel analytically,
+//   (g1 - g2) sinh(eta) = [sinh(eta A1) + sinh(eta A2) - sinh(eta A3) - sinh(eta A4)] / 2,
+//   A1 = 2 - zD - dD,  A2 = zD - dD,  A3 = lD1 + 1 - zD,  A4 = lD1 - 1 + zD      (all in [-1, 1]),
+// and sinh(eta A) / sinh(eta) = e^{-eta (1 - A)} (1 - e^{-2 eta A}) / (1 - e^{-2 eta}) neither overflows nor cancels.
+// The fast evaluators use the cosh/sinh form of the same identity inside their range (ucf_fastpath.h); this one serves the
+// items that point_kernel resumes beyond it, so that a series never changes from clean values to that noise in mid-course
+// (tools/fuzz_hunt.py: errors of 3e-2 ... 5 in h where the reference itself is good to 1e-9).
+UCF_DEV cplx sinh_ratio_(cplx eta, double A, cplx one_minus_E2)
+{
+    const double a = fabs(A);
+    const cplx e1 = cexp_(cscale(eta, -(1.0 - a)));
+    const cplx e2 = cexp_(cscale(eta, -2.0 * a));
+    const cplx r = cmul(e1, cdiv(rsub(1.0, e2), one_minus_E2));
+    return (A < 0.0) ? cneg(r) : r;
+}
+UCF_DEV cplx lay3_udp_scaled(const ucf_dev_params& P, cplx eta, double zD)
+{
+    const cplx omE2 = rsub(1.0, cexp_(cscale(eta, -2.0)));
+    const cplx t1 = sinh_ratio_(eta, 2.0 - zD - P.dD, omE2), t2 = sinh_ratio_(eta, zD - P.dD, omE2);
+    const cplx t3 = sinh_ratio_(eta, P.lD1 + 1.0 - zD, omE2), t4 = sinh_ratio_(eta, P.lD1 - 1.0 + zD, omE2);
+    return rscale(0.5, csub(cadd(t1, t2), cadd(t3, t4)));
+}
+// the reference's value where it is not finite (its in-band rules key on that), else the clean one
+UCF_DEV cplx lay3_pick(cplx reference_value, cplx clean_value) { return c_is_finite(reference_value) ? clean_value : reference_value; }
 #endif
 
 template <int FAMILY>   // 0 Theis, 1 Hantush, 2 water-table (models 3,4,5), 3 MN-Malama, 4 MN-FD, 5 Hantush+storage
@@ -484,16 +515,34 @@ UCF_DEV cplx sample_z(const ucf_dev_params& P, const sample_common& S, int iz)
         }
         return cmul(S.hs_pre, uDp);                                                             // :299
     }
-    if (FAMILY == 1) return hantush_z(P, S, zD, lay, chz);
+#if UCF_FAST
+    // (resumed items of the fast flavour: a depth above the screen top takes the cancellation-free forms of its Hantush
+    //  factor and of the water-table value the closures are built on; see lay3_udp_scaled)
+    const bool clean3 = S.clean3 && lay == 3 && !(FAMILY == 2 && P.model == 4);
+#else
+    const bool clean3 = false;
+#endif
+    cplx uH = cmake(0.0, 0.0), top = S.top, fd_s1 = S.fd_s1;
+    if (!(FAMILY == 2 && P.model == 4)) uH = hantush_z(P, S, zD, lay, chz);
+#if UCF_FAST
+    if (clean3) {
+        uH = lay3_pick(uH, cdivr(cmul(lay3_udp_scaled(P, S.eta, zD), S.th), P.bD));
+        if (FAMILY != 1) {
+            const cplx topc = lay3_pick(S.top, cdivr(cmul(lay3_udp_scaled(P, S.eta, 1.0), S.th), P.bD));
+            if (FAMILY == 4 && S.fd_use && c_is_finite(S.top) && cabs_(S.top) > 0.0) fd_s1 = cmul(S.fd_s1, cdiv(topc, S.top));   // sigma(1) is linear in top (:513-523)
+            top = topc;
+        }
+    }
+#endif
+    if (FAMILY == 1) return uH;
     if (FAMILY == 2) {
-        const cplx u = (P.model == 4) ? S.th : hantush_z(P, S, zD, lay, chz);
-        if (S.small_eta) return csub(u, cdiv(cmul(S.top, chz), S.den));                         // :85-87
-        return csub(u, cdiv(cmul(S.top, cexp_(cscale(S.eta, zD - 1.0))), S.den));               // :89-91
+        const cplx u = (P.model == 4) ? S.th : uH;
+        if (S.small_eta) return csub(u, cdiv(cmul(top, chz), S.den));                           // :85-87
+        return csub(u, cdiv(cmul(top, cexp_(cscale(S.eta, zD - 1.0))), S.den));                 // :89-91
     }
     // FAMILY 4
-    const cplx sH = hantush_z(P, S, zD, lay, chz);
-    if (S.fd_use) return cadd(sH, cmul(S.fd_s1, chz));                                          // :522-523
-    return sH;                                                                                  // :525
+    if (S.fd_use) return cadd(uH, cmul(fd_s1, chz));                                            // :522-523
+    return uH;                                                                                  // :525
 }
 
 }  // namespace UCF_NS
@@ -1223,8 +1272,12 @@ point_kernel(const ucf_dev_params P0, int npts, int per_point, int nr, int nsv, 
         for (; n < nabs; n++) {
             const double2 aa = row[n];
             sample_common S;
+            S.clean3 = resume;
             sample_prepare<FAMILY>(P, aa.x, p, need_lay1, S, fdbuf, lane, lane_aux);
-            for (int z = 0; z < nz; z++) accumulate(n, aa.y, z, sample_z<FAMILY>(P, S, z));
+            for (int z = 0; z < nz; z++) {
+                const cplx f = sample_z<FAMILY>(P, S, z);
+                accumulate(n, aa.y, z, f);
+            }
         }
         finish_item<LAYOUT, UCF_PART>(P, accTS, scr, areas_lds ? accGL : nullptr, areas, arg, W, pt, tD, tee, p, st, nt, ir0, totlap,
                                       hout, dhout);
@@ -1399,6 +1452,7 @@ integrate_generic_kernel(const ucf_dev_params P, int npts, int per_point, int nr
         for (int n = 0; n < nabs; n++) {
             const double2 aa = row[n];
             sample_common S;
+            S.clean3 = false;
             sample_prepare<FAMILY>(P, aa.x, p, need_lay1, S, fdbuf, lane, lane_aux);
             const bool ts = n < N;
             for (int z = 0; z < nz; z++) {
@@ -1624,6 +1678,7 @@ samples_kernel(const ucf_dev_params P, int n_a, const double* __restrict__ av, d
     const cplx lt = lap_time(P, p);
     const double aj = a * j0(a * rD);
     sample_common S;
+    S.clean3 = false;
     bool fast = false;
 #if UCF_FAST
     fast_common F;
