@@ -94,7 +94,7 @@ for W in ("c2", "c2pp", "c3", "c4", "c5"):
     print(W, line["config"]["build_id"], {k[-44:]: (round(v.get("fp64_flop_per_launch", 0) / 1e12, 3), round(v.get("valu_busy", 0), 3),
                                                     round(v.get("valu_per_wave_abscissa", 0), 1)) for k, v in kern.items() if "integrate" in k})
 json.dump(prof, open(prof_path, "w"), indent=1, sort_keys=True)
-for n in ("bench_default", "bench_faithful", "bench_c2pp", "bench_c3", "bench_c4", "bench_c5"):
+for n in ("bench_default", "bench_faithful", "bench_c2pp", "bench_c3", "bench_c4", "bench_c5", "bench_gpus2_strong", "bench_gpus2_weak"):
     line = bench_line(os.path.join(G, n + ".log"))
     if line:
         json.dump(line, open(os.path.join(P, f"{tag}_{n}.json"), "w"))

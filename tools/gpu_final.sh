@@ -37,3 +37,7 @@ timeout -k 10 600 python bench.py --mode faithful --no-cpu > gpurun_out/bench_fa
 for W in c2pp c3 c4 c5; do
   timeout -k 10 600 python bench.py --no-cpu --workload $W --steps 3 > gpurun_out/bench_$W.log 2> gpurun_out/bench_$W.err; echo "[bench $W] rc=$?"
 done
+# rehearsal of the N > 1 path on this one-GPU box: bench.py starts its own two ranks (both on cuda:0, gloo), strong and weak
+for S in strong weak; do
+  UCF_BENCH_ONE_DEVICE=1 UCF_BENCH_BACKEND=gloo timeout -k 10 600 python bench.py --gpus 2 --steps 3 --scaling $S > gpurun_out/bench_gpus2_$S.log 2> gpurun_out/bench_gpus2_$S.err; echo "[bench --gpus 2 $S] rc=$?"
+done

@@ -1361,6 +1361,7 @@ integrate_kernel(const ucf_dev_params P0, int npts, int per_point, int nr, int n
             const double2 nxt = row[n + 1 < nabs ? n + 1 : n];
             const bool ts = n < N;
             const double w = ts ? 0.0 : P.gl_w[m];
+            F.salt = n;
             if (!__all(fast_eta<FAMILY>(P, LC, aa.x, F))) break;
             fast_common_terms<FAMILY, FOLD, LAY3>(P, LC, aa.x, need_lay1, F, need_lay3, need_lay12);
             const int n1 = n + 1;
@@ -1687,6 +1688,7 @@ samples_kernel(const ucf_dev_params P, int n_a, const double* __restrict__ av, d
         for (int k = threadIdx.x; k < UCF_SC_ENTRIES; k += UCF_WAVE) lds[k] = gt[k];
         __syncthreads();
         F.sct = lds;
+        F.salt = ia;
     }
     if (FAMILY == 1 || FAMILY == 2 || FAMILY == 4) {
         const lane_consts LC = make_lane_consts(P, p, lt);

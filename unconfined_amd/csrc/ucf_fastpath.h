@@ -51,7 +51,7 @@ UCF_DEV double exp_pos(double x)
     return ldexp(q, (int)k);
 }
 
-UCF_DEV fprim prim(double x, double y, const double2* __restrict__ sct)
+UCF_DEV fprim prim(double x, double y, const double2* __restrict__ sct, int salt)
 {
     fprim f;
     const double ax = fabs(x);
@@ -62,7 +62,6 @@ UCF_DEV fprim prim(double x, double y, const double2* __restrict__ sct)
     double s;
     if (ax < 0.35) {
         const double x2 = ax * ax;
-        const int salt = __builtin_amdgcn_readfirstlane(__double2hiint(x));
         double pl = addk(mulk(x2, UCF_KHERE(1.0 / 6227020800.0, salt)), UCF_KHERE(1.0 / 39916800.0, salt));
         pl = fmak(pl, x2, UCF_KHERE(1.0 / 362880.0, salt));
         pl = fmak(pl, x2, UCF_KHERE(1.0 / 5040.0, salt));
@@ -73,7 +72,7 @@ UCF_DEV fprim prim(double x, double y, const double2* __restrict__ sct)
         s = 0.5 * (e - ei);
     }
     f.sh = copysign(s, x);
-    sincos_tab_(y, sct, &f.sn, &f.cs);     // |y| < 1e6: fast_eta() vouches for it
+    sincos_tab_(y, sct, &f.sn, &f.cs, salt);     // |y| < 1e6: fast_eta() vouches for it
     return f;
 }
 // primitive of x1 - x2, y1 - y2 from the primitives of (x1, y1) and (x2, y2), 0 <= x2 <= x1: the real
@@ -97,11 +96,11 @@ UCF_DEV cplx psinh(const fprim& f) { return cmake(f.sh * f.cs, f.ch * f.sn); }
 UCF_DEV cplx pexpneg(const fprim& f) { return cmake(f.ei * f.cs, -(f.ei * f.sn)); }
 
 // exp(-(x + iy)) for x >= 0 on its own: no reciprocal, no cosh/sinh
-UCF_DEV cplx expneg_direct(double x, double y, const double2* __restrict__ sct)
+UCF_DEV cplx expneg_direct(double x, double y, const double2* __restrict__ sct, int salt)
 {
     const double ei = exp_pos(-x);
     double sn, cs;
-    sincos_tab_(y, sct, &sn, &cs);
+    sincos_tab_(y, sct, &sn, &cs, salt);
     return cmake(ei * cs, -(ei * sn));
 }
 
@@ -153,6 +152,7 @@ UCF_DEV lane_consts make_lane_consts(const ucf_dev_params& P, cplx p, cplx lt)
 
 struct fast_common {
     const double2* sct;  // sin/cos table in LDS (sincos_tab_), set once per kernel
+    int salt;            // wave-uniform, changes per abscissa (the loop counter): pins locally materialised constants to their place
     cplx th, eta, ff1, ff2, inv_she, she, che, top, g3, inv_den, ex1;   // ex1 = exp(-eta)
     fprim p1;            // primitive of eta itself (valid when have_p1)
     bool have_p1;
@@ -216,7 +216,7 @@ UCF_DEV void fast_common_terms(const ucf_dev_params& P, const lane_consts& L, do
     S.have_p1 = need_p1 && !z2;      // kept only where fast_hantush_z derives the primitive of eta (1 - zD) from it
     fprim p1;
     if (need_p1) {
-        p1 = prim(S.eta.re, S.eta.im, S.sct);
+        p1 = prim(S.eta.re, S.eta.im, S.sct, S.salt);
         if (!z2) S.p1 = p1;
         S.che = pcosh(p1);
         S.she = psinh(p1);
@@ -226,10 +226,10 @@ UCF_DEV void fast_common_terms(const ucf_dev_params& P, const lane_consts& L, do
     }
     if (hantush) {
         fprim pd;
-        if (!z1) { pd = prim(S.eta.re * P.dD, S.eta.im * P.dD, S.sct); S.ff1 = psinh(pd); }           // :176
+        if (!z1) { pd = prim(S.eta.re * P.dD, S.eta.im * P.dD, S.sct, S.salt); S.ff1 = psinh(pd); }           // :176
         else S.ff1 = cmake(0.0, 0.0);
         fprim pl;
-        if (!z2) { pl = prim(S.eta.re * P.lD1, S.eta.im * P.lD1, S.sct); S.ff2 = psinh(pl); }         // :177
+        if (!z2) { pl = prim(S.eta.re * P.lD1, S.eta.im * P.lD1, S.sct, S.salt); S.ff2 = psinh(pl); }         // :177
         else S.ff2 = cmake(0.0, 0.0);
         if (!(z1 && z2) || need_lay1) S.inv_she = cinv_auto(S.she);
         if (need_lay1) {                                                                        // :183-184
@@ -244,7 +244,7 @@ UCF_DEV void fast_common_terms(const ucf_dev_params& P, const lane_consts& L, do
                     cplx g1;
                     if (z1) g1 = cmake(1.0, 0.0);
                     else if (P.share_g1top) g1 = pcosh(pd);
-                    else { const double c = P.dD1 - 1.0; g1 = pcosh(prim(S.eta.re * c, S.eta.im * c, S.sct)); }
+                    else { const double c = P.dD1 - 1.0; g1 = pcosh(prim(S.eta.re * c, S.eta.im * c, S.sct, S.salt)); }
                     const cplx udp = csub(g1, cmul(cadd(cmul(S.ff1, S.che), S.ff2), S.inv_she));
                     S.top = cmul(udp, S.th);                                                    // :200 (x fast_scale)
                 }
@@ -261,7 +261,7 @@ UCF_DEV void fast_common_terms(const ucf_dev_params& P, const lane_consts& L, do
                         // abscissae with a small eta (1 - dD) get their own primitive
                         const double x1 = S.eta.re * P.dD1;
                         if (__builtin_amdgcn_ballot_w64(!(x1 >= 1.0)) == 0) sd1 = psinh(prim_difference(p1, pd));
-                        else sd1 = psinh(prim(x1, S.eta.im * P.dD1, S.sct));
+                        else sd1 = psinh(prim(x1, S.eta.im * P.dD1, S.sct, S.salt));
                     }
                     const cplx udp = cmul(z2 ? sd1 : csub(sd1, S.ff2), S.inv_she);
                     S.top3 = cmul(udp, S.th);
@@ -328,7 +328,7 @@ UCF_DEV cplx fast_hantush_z(const ucf_dev_params& P, const fast_common& S, doubl
     const bool need_chz = (lay == 1) || !z1 || (FAMILY == 2 && S.any_small) || FAMILY == 4;
     cplx chz = cmake(1.0, 0.0);
     fprim pz;
-    if (need_chz) { pz = prim(S.eta.re * zD, S.eta.im * zD, S.sct); chz = pcosh(pz); }
+    if (need_chz) { pz = prim(S.eta.re * zD, S.eta.im * zD, S.sct, S.salt); chz = pcosh(pz); }
     *chz_out = chz;
     cplx udp;
     if (lay == 1) {
@@ -339,14 +339,14 @@ UCF_DEV cplx fast_hantush_z(const ucf_dev_params& P, const fast_common& S, doubl
         fprim p1z;
         if (z2 && FAMILY == 2 && S.any_large) {                  // only exp(eta (zD - 1)) is wanted
             const double c = 1.0 - zD;
-            *exz_out = expneg_direct(S.eta.re * c, S.eta.im * c, S.sct);
+            *exz_out = expneg_direct(S.eta.re * c, S.eta.im * c, S.sct, S.salt);
         }
         if (need_1z) {
 #ifndef UCF_NO_PRIM_DIFFERENCE
             if (need_chz && S.have_p1 && zD >= 0.0 && zD <= 1.0) p1z = prim_difference(S.p1, pz);     // eta (1 - zD)
             else
 #endif
-            { const double c = 1.0 - zD; p1z = prim(S.eta.re * c, S.eta.im * c, S.sct); }
+            { const double c = 1.0 - zD; p1z = prim(S.eta.re * c, S.eta.im * c, S.sct, S.salt); }
         }
         if (!z2 && FAMILY == 2 && S.any_large) *exz_out = pexpneg(p1z);                         // exp(eta*(zD-1))
         cplx f2c = cmake(0.0, 0.0);
@@ -363,8 +363,8 @@ UCF_DEV cplx fast_hantush_z(const ucf_dev_params& P, const fast_common& S, doubl
             // the large parts cancel analytically:
             //   (g1 - g2) sinh(eta) = sinh(eta (2 - zD - dD))/2 + sinh(eta (zD - dD))/2 - sinh(eta lD1) cosh(eta (1 - zD))
             const double ca = 2.0 - zD - P.dD, cb = zD - P.dD;
-            const cplx sa = psinh(prim(S.eta.re * ca, S.eta.im * ca, S.sct));
-            const cplx sb = psinh(prim(S.eta.re * cb, S.eta.im * cb, S.sct));
+            const cplx sa = psinh(prim(S.eta.re * ca, S.eta.im * ca, S.sct, S.salt));
+            const cplx sb = psinh(prim(S.eta.re * cb, S.eta.im * cb, S.sct, S.salt));
             // (explicit FMAs: the same bits in every instantiation of the kernel)
             const cplx num = cmake(__builtin_fma(0.5, sa.re + sb.re, -f2c.re), __builtin_fma(0.5, sa.im + sb.im, -f2c.im));
             udp = cmul(num, S.inv_she);
@@ -388,11 +388,11 @@ UCF_DEV cplx fast_sample_z(const ucf_dev_params& P, const fast_common& S, int iz
     cplx u;
     if (P.model == 4) {
         u = S.th;
-        if (S.any_small) chz = pcosh(prim(S.eta.re * zD, S.eta.im * zD, S.sct));
-        if (S.any_large) { const double c = 1.0 - zD; exz = expneg_direct(S.eta.re * c, S.eta.im * c, S.sct); }
+        if (S.any_small) chz = pcosh(prim(S.eta.re * zD, S.eta.im * zD, S.sct, S.salt));
+        if (S.any_large) { const double c = 1.0 - zD; exz = expneg_direct(S.eta.re * c, S.eta.im * c, S.sct, S.salt); }
     } else {
         u = fast_hantush_z<2, FOLD, LAY3>(P, S, zD, lay, &chz, &exz);
-        if (S.any_large && lay == 1) { const double c = 1.0 - zD; exz = expneg_direct(S.eta.re * c, S.eta.im * c, S.sct); }
+        if (S.any_large && lay == 1) { const double c = 1.0 - zD; exz = expneg_direct(S.eta.re * c, S.eta.im * c, S.sct, S.salt); }
     }
     const cplx top = (!FOLD && LAY3 && P.model != 4 && lay == 3) ? S.top3 : S.top;
     if (S.small_eta) return csub(u, cmul(cmul(top, chz), S.inv_den));                           // :85-87

@@ -246,9 +246,9 @@ UCF_DEV void sincos_medium_(double x, double* sn, double* cs)
 //     results keep their relative accuracy next to the zeros of sin and cos: 0 + (1 * sin y + 0).
 // Error < 1.5 ulp (table entry 0.5, correction 0.5 ulp of a term <= 0.0123, final addition 0.5).
 #define UCF_SC_N 256
-UCF_DEV void sincos_tab_(double x, const double2* __restrict__ tab, double* sn, double* cs)
+// (salt: any wave-uniform value that changes per loop iteration, see sgpr_const_here)
+UCF_DEV void sincos_tab_(double x, const double2* __restrict__ tab, double* sn, double* cs, int salt)
 {
-    const int salt = __builtin_amdgcn_readfirstlane(__double2hiint(x));
 #define K(c) UCF_KHERE(c, salt)
     const double MAGIC = 6755399441055744.0;                                   // 1.5 * 2^52
     const double t = fmak(x, K(4.07436654315252059568e+01), MAGIC);            // x * (128/pi) + magic
