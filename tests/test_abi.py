@@ -103,3 +103,38 @@ def test_product_does_not_touch_the_oracle():
                 assert "oracle_lib" not in text and "ucf_oracle" not in text and "libucf_oracle" not in text, fn
     out = subprocess.run(["ldd", ucflib.LIB_PATH], capture_output=True, text=True).stdout
     assert "oracle" not in out
+
+
+def test_host_only_entries_work_without_a_gpu(so, oracle):
+    """what the reference computes in read_input needs no device: the partition rule of the multi-GPU entry points,
+    read_input's checks + non-dimensionalisation (bit for bit the oracle's, hence the reference's), and the header that a
+    reference-side Fortran binding would include compiles as plain C"""
+    lo, hi = C.c_int(), C.c_int()
+    assert so.ucf_shard_rows(1024, 8, 3, C.byref(lo), C.byref(hi)) == 0 and (lo.value, hi.value) == (384, 512)
+    assert so.ucf_shard_rows(10, 4, 3, C.byref(lo), C.byref(hi)) == 0 and (lo.value, hi.value) == (9, 10)
+    assert so.ucf_shard_rows(2, 4, 3, C.byref(lo), C.byref(hi)) == 0 and lo.value == hi.value        # an empty shard
+    for bad in ((10, 0, 0), (10, 2, 2), (-1, 2, 0)):
+        assert so.ucf_shard_rows(*bad, C.byref(lo), C.byref(hi)) == -11
+    for name in ("neuman74_partpen", "c3_moench", "mishra_malama", "hstorage_partpen_lay1"):
+        P = params_from_deck(Deck.read(os.path.join(ROOT, "tests", "golden", "decks", name + ".in")))
+        D = UcfDerived()
+        assert so.ucf_nondimensionalise(C.byref(P), C.byref(D)) == 0
+        Do = oracle.nondim(P)
+        for f, _ in UcfDerived._fields_:
+            a, b = getattr(D, f), getattr(Do, f)
+            assert (list(a) == list(b)) if f == "MoenchGamma" else (a == b), (name, f)
+    P.b = -1.0
+    assert so.ucf_nondimensionalise(C.byref(P), C.byref(D)) == -3
+    assert len(so.ucf_build_id()) == 16
+
+
+def test_device_entries_say_no_device_without_a_gpu(so):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    n = C.c_int(7)
+    assert so.ucf_device_count(C.byref(n)) == -12 and n.value == 0
+    P = params_from_deck(Deck.read(os.path.join(ROOT, "tests", "golden", "decks", "neuman74_partpen.in")))
+    h = C.c_void_p()
+    assert so.ucf_plan_create_on(C.byref(P), 0, C.byref(h)) == -12 and not h.value
+    assert b"no CPU fallback" in so.ucf_last_error()

@@ -77,8 +77,9 @@ for W in ("c2", "c2pp", "c3", "c4", "c5"):
             e["fp64_flop_per_launch"] = 64.0 * (arith + c["SQ_INSTS_VALU_FMA_F64"])
             if "integrate" in k and c.get("SQ_WAVES"):
                 e["fp64_arith_per_wave_abscissa"] = arith / c["SQ_WAVES"] / NABS[W]
-        if c.get("GRBM_GUI_ACTIVE") and "SQ_ACTIVE_INST_VALU" in c:
-            e["valu_busy"] = c["SQ_ACTIVE_INST_VALU"] * 4 / (c["GRBM_GUI_ACTIVE"] / 8 * 1024)
+        # (only for the long kernels: GRBM_GUI_ACTIVE of a 2 ms kernel is dominated by ramp-up and drain and the ratio overshoots 1)
+        if c.get("GRBM_GUI_ACTIVE") and "SQ_ACTIVE_INST_VALU" in c and ("integrate" in k or "point_kernel" in k):
+            e["valu_busy"] = min(1.0, c["SQ_ACTIVE_INST_VALU"] * 4 / (c["GRBM_GUI_ACTIVE"] / 8 * 1024))
         if "integrate" in k and c.get("SQ_WAVES") and "SQ_INSTS_VALU" in c:
             e["valu_per_wave_abscissa"] = c["SQ_INSTS_VALU"] / c["SQ_WAVES"] / NABS[W]
             e["salu_per_wave_abscissa"] = c["SQ_INSTS_SALU"] / c["SQ_WAVES"] / NABS[W]
@@ -93,6 +94,11 @@ for W in ("c2", "c2pp", "c3", "c4", "c5"):
         "launches_per_step": line["roofline"].get("kernel_launches_per_step"), "workload": line["config"]["workload"], "kernels": kern}
     print(W, line["config"]["build_id"], {k[-44:]: (round(v.get("fp64_flop_per_launch", 0) / 1e12, 3), round(v.get("valu_busy", 0), 3),
                                                     round(v.get("valu_per_wave_abscissa", 0), 1)) for k, v in kern.items() if "integrate" in k})
+try:        # where there is a git checkout (the build container, not the GPU box): the commit the evidence was collected at
+    import subprocess
+    prof["collected_at_git_head"] = subprocess.run(["git", "-C", R, "rev-parse", "HEAD"], capture_output=True, text=True, check=True).stdout.strip()
+except Exception:
+    pass
 json.dump(prof, open(prof_path, "w"), indent=1, sort_keys=True)
 for n in ("bench_default", "bench_faithful", "bench_c2pp", "bench_c3", "bench_c4", "bench_c5", "bench_gpus2_strong", "bench_gpus2_weak"):
     line = bench_line(os.path.join(G, n + ".log"))
