@@ -282,6 +282,8 @@ int ucf_bessel_k01(int n, const double* z_re_im, double* k_re_im, int* ierr);
 /* the (sin, cos)(k pi / 128), k = 0..255, table that every plan uploads for the fast flavour's evaluators (host code, no
  * GPU needed; tab[256][2]) */
 int ucf_sincos_table(double* tab);
+/* and the 2^(j/128), j = 0..127, table behind it (exp of the fast flavour's evaluators; tab[128][2] = (hi, lo)) */
+int ucf_exp2_table(double* tab);
 
 /* ---- measurement helper: sustained fp64 FMA rate of the device ---- */
 int ucf_fp64_fma_peak(double* tflops);

@@ -1300,6 +1300,10 @@ point_kernel(const ucf_dev_params P0, int npts, int per_point, int nr, int nsv, 
 #ifndef UCF_UNFOLD_WAVES
 #define UCF_UNFOLD_WAVES 4
 #endif
+// constants of sincos_tab_ / exp_tab_ kept in VGPRs (sc_ctx::kv)
+#ifndef UCF_KV
+#define UCF_KV(FAMILY, FOLD) ((FAMILY) == 4 ? 0 : (FOLD) ? 1 : 4)
+#endif
 // WAVES per SIMD the register budget is cut for: as many as the LDS footprint admits (6 for nz = 1 at R = 4,
 // fully penetrating; 5; else 4)
 // UCF_IWPB waves per workgroup: they share nothing but the sin/cos table of sincos_tab_ in LDS (4 KB, copied once from
@@ -1348,7 +1352,7 @@ integrate_kernel(const ucf_dev_params P0, int npts, int per_point, int nr, int n
         double2* __restrict__ areas = sti + (size_t)(R + 1) * nz * UCF_WAVE;
         for (int s = 0; s < (R + 1) * nz; s++) lds_st(wlds, s, lane, cmake(0.0, 0.0));
         fast_common F;
-        F.sct = sct;
+        sc_ctx_init(F.sc, sct, UCF_KV(FAMILY, FOLD));
 
         // abscissae increase monotonically (tanh-sinh on [0,arg], then the J0 intervals), so does Re(eta):
         // the fast evaluation is valid for a leading run of abscissae; point_kernel finishes the rest.
@@ -1361,7 +1365,7 @@ integrate_kernel(const ucf_dev_params P0, int npts, int per_point, int nr, int n
             const double2 nxt = row[n + 1 < nabs ? n + 1 : n];
             const bool ts = n < N;
             const double w = ts ? 0.0 : P.gl_w[m];
-            F.salt = n;
+            F.sc.salt = n;
             if (!__all(fast_eta<FAMILY>(P, LC, aa.x, F))) break;
             fast_common_terms<FAMILY, FOLD, LAY3>(P, LC, aa.x, need_lay1, F, need_lay3, need_lay12);
             const int n1 = n + 1;
@@ -1687,8 +1691,8 @@ samples_kernel(const ucf_dev_params P, int n_a, const double* __restrict__ av, d
         const double2* __restrict__ gt = (const double2*)P.sc_tab;
         for (int k = threadIdx.x; k < UCF_SC_ENTRIES; k += UCF_WAVE) lds[k] = gt[k];
         __syncthreads();
-        F.sct = lds;
-        F.salt = ia;
+        sc_ctx_init(F.sc, lds, 0);
+        F.sc.salt = ia;
     }
     if (FAMILY == 1 || FAMILY == 2 || FAMILY == 4) {
         const lane_consts LC = make_lane_consts(P, p, lt);

@@ -4,8 +4,10 @@
 // Same formulas as laplace_hankel_solutions.f90:64-93,133-202 (cited per line below), evaluated
 // with the minimum of work a wave needs:
 //   * every cosh/sinh/exp of eta*c comes from ONE primitive per distinct real factor c:
-//     E = exp(|Re|), 1/E by Newton reciprocal, sincos(Im) by a two-stage Cody-Waite reduction
-//     and the fdlibm kernels; cosh, sinh and exp(-.) of that argument are 2-4 multiplies away;
+//     E = exp(|Re|) and sincos(Im) from tables in LDS (exp_tab_, sincos_tab_: ucf_math.h), 1/E by a
+//     Newton reciprocal; cosh, sinh and exp(-.) of that argument are 2-4 multiplies away;
+//   * factors that differ by a rounding error share a primitive (cosh(eta (dD1 - 1)) next to sinh(eta dD):
+//     first-order correction in the exactly known difference, fast_common_terms);
 //   * divisions by per-lane constants (p, kappa, bD, Moench sum) are reciprocals hoisted out of
 //     the abscissa loop; sinh(eta) and the closure denominator are inverted once per sample;
 //   * exact zeros are folded at plan level: a fully penetrating well (d = 0, l = b) has
@@ -21,41 +23,12 @@ struct fprim {
     double ch, sh, ei, sn, cs;    // cosh(x), sinh(x), exp(-|x|), sin(y), cos(y)
 };
 
-// exp(x), |x| <= 709 (underflows to 0 / subnormals below that like ldexp does).  k = rint(x/ln2), r = x - k ln2 (two-part),
-// degree-11 near-minimax polynomial in r, scaled by 2^k.
-UCF_DEV double exp_pos(double x)
+UCF_DEV fprim prim(double x, double y, const sc_ctx& sc)
 {
-#ifdef UCF_EXP_LOCAL_CONSTANTS
-    const int salt = __builtin_amdgcn_readfirstlane(__double2hiint(x));
-#define K(c) UCF_KHERE(c, salt)
-#else
-#define K(c) (c)
-#endif
-    const double k = __builtin_rint(x * 1.4426950408889634074);      // (plain product: lets |x| / -x fold into the operand)
-    double r = __builtin_fma(-k, 6.93147180369123816490e-01, x);
-    r = __builtin_fma(-k, 1.90821492927058770002e-10, r);
-    // 1 + r + r^2 s(r), s of degree 9 interpolating (e^r - 1 - r)/r^2 at the Chebyshev nodes of |r| <= 0.34665
-    // (computed in 70-digit arithmetic): max relative error 1.6e-17 with these double coefficients
-    double q = addk(mulk(r, K(2.5100397137931663e-08)), K(2.762010358488696e-07));
-    q = fmak(q, r, K(2.755726843551756e-06));
-    q = fmak(q, r, K(2.4801521264122017e-05));
-    q = fmak(q, r, K(0.00019841269863069374));
-    q = fmak(q, r, K(0.0013888888917234206));
-    q = fmak(q, r, K(0.008333333333330058));
-    q = fmak(q, r, K(0.04166666666662409));
-    q = fmak(q, r, K(0.16666666666666669));
-    q = fmak(q, r, K(0.5000000000000001));
-#undef K
-    q = __builtin_fma(q, r, 1.0);
-    q = __builtin_fma(q, r, 1.0);
-    return ldexp(q, (int)k);
-}
-
-UCF_DEV fprim prim(double x, double y, const double2* __restrict__ sct, int salt)
-{
+    const int salt = sc.salt;
     fprim f;
     const double ax = fabs(x);
-    const double e = exp_pos(ax);
+    const double e = exp_tab_(ax, sc);
     const double ei = fast_rcp(e);
     f.ei = ei;
     f.ch = 0.5 * (e + ei);
@@ -72,7 +45,7 @@ UCF_DEV fprim prim(double x, double y, const double2* __restrict__ sct, int salt
         s = 0.5 * (e - ei);
     }
     f.sh = copysign(s, x);
-    sincos_tab_(y, sct, &f.sn, &f.cs, salt);     // |y| < 1e6: fast_eta() vouches for it
+    sincos_tab_(y, sc, &f.sn, &f.cs);     // |y| < 1e6: fast_eta() vouches for it
     return f;
 }
 // primitive of x1 - x2, y1 - y2 from the primitives of (x1, y1) and (x2, y2), 0 <= x2 <= x1: the real
@@ -96,11 +69,11 @@ UCF_DEV cplx psinh(const fprim& f) { return cmake(f.sh * f.cs, f.ch * f.sn); }
 UCF_DEV cplx pexpneg(const fprim& f) { return cmake(f.ei * f.cs, -(f.ei * f.sn)); }
 
 // exp(-(x + iy)) for x >= 0 on its own: no reciprocal, no cosh/sinh
-UCF_DEV cplx expneg_direct(double x, double y, const double2* __restrict__ sct, int salt)
+UCF_DEV cplx expneg_direct(double x, double y, const sc_ctx& sc)
 {
-    const double ei = exp_pos(-x);
+    const double ei = exp_tab_(-x, sc);
     double sn, cs;
-    sincos_tab_(y, sct, &sn, &cs, salt);
+    sincos_tab_(y, sc, &sn, &cs);
     return cmake(ei * cs, -(ei * sn));
 }
 
@@ -151,8 +124,7 @@ UCF_DEV lane_consts make_lane_consts(const ucf_dev_params& P, cplx p, cplx lt)
 }
 
 struct fast_common {
-    const double2* sct;  // sin/cos table in LDS (sincos_tab_), set once per kernel
-    int salt;            // wave-uniform, changes per abscissa (the loop counter): pins locally materialised constants to their place
+    sc_ctx sc;           // sin/cos table in LDS + constants (sincos_tab_), set once per kernel; sc.salt = the loop counter
     cplx th, eta, ff1, ff2, inv_she, she, che, top, g3, inv_den, ex1;   // ex1 = exp(-eta)
     fprim p1;            // primitive of eta itself (valid when have_p1)
     bool have_p1;
@@ -186,8 +158,8 @@ UCF_DEV bool fast_eta(const ucf_dev_params& P, const lane_consts& L, double a, f
     }
     {   // eta = sqrt(q/kappa), Re q > 0                                                         (:69,172)
         const double qr = q.re * P.inv_kappa, qi = q.im * P.inv_kappa;
-        double d, r, hr;
-        sqrt_hrsqrt(__builtin_fma(qr, qr, qi * qi), &d, &hr);
+        double r, hr;
+        const double d = sqrt_only(__builtin_fma(qr, qr, qi * qi));
         sqrt_hrsqrt(0.5 * (d + qr), &r, &hr);
         S.eta = cmake(r, qi * hr);
     }
@@ -216,7 +188,7 @@ UCF_DEV void fast_common_terms(const ucf_dev_params& P, const lane_consts& L, do
     S.have_p1 = need_p1 && !z2;      // kept only where fast_hantush_z derives the primitive of eta (1 - zD) from it
     fprim p1;
     if (need_p1) {
-        p1 = prim(S.eta.re, S.eta.im, S.sct, S.salt);
+        p1 = prim(S.eta.re, S.eta.im, S.sc);
         if (!z2) S.p1 = p1;
         S.che = pcosh(p1);
         S.she = psinh(p1);
@@ -226,10 +198,10 @@ UCF_DEV void fast_common_terms(const ucf_dev_params& P, const lane_consts& L, do
     }
     if (hantush) {
         fprim pd;
-        if (!z1) { pd = prim(S.eta.re * P.dD, S.eta.im * P.dD, S.sct, S.salt); S.ff1 = psinh(pd); }           // :176
+        if (!z1) { pd = prim(S.eta.re * P.dD, S.eta.im * P.dD, S.sc); S.ff1 = psinh(pd); }           // :176
         else S.ff1 = cmake(0.0, 0.0);
         fprim pl;
-        if (!z2) { pl = prim(S.eta.re * P.lD1, S.eta.im * P.lD1, S.sct, S.salt); S.ff2 = psinh(pl); }         // :177
+        if (!z2) { pl = prim(S.eta.re * P.lD1, S.eta.im * P.lD1, S.sc); S.ff2 = psinh(pl); }         // :177
         else S.ff2 = cmake(0.0, 0.0);
         if (!(z1 && z2) || need_lay1) S.inv_she = cinv_auto(S.she);
         if (need_lay1) {                                                                        // :183-184
@@ -243,8 +215,9 @@ UCF_DEV void fast_common_terms(const ucf_dev_params& P, const lane_consts& L, do
                 if (need_lay12) {
                     cplx g1;
                     if (z1) g1 = cmake(1.0, 0.0);
-                    else if (P.share_g1top) g1 = pcosh(pd);
-                    else { const double c = P.dD1 - 1.0; g1 = pcosh(prim(S.eta.re * c, S.eta.im * c, S.sct, S.salt)); }
+                    else if (P.share_g1top == 1) g1 = pcosh(pd);
+                    else if (P.share_g1top == 2) g1 = csub(pcosh(pd), cmul(rscale(P.g1_delta, S.eta), S.ff1));
+                    else { const double c = P.dD1 - 1.0; g1 = pcosh(prim(S.eta.re * c, S.eta.im * c, S.sc)); }
                     const cplx udp = csub(g1, cmul(cadd(cmul(S.ff1, S.che), S.ff2), S.inv_she));
                     S.top = cmul(udp, S.th);                                                    // :200 (x fast_scale)
                 }
@@ -261,7 +234,7 @@ UCF_DEV void fast_common_terms(const ucf_dev_params& P, const lane_consts& L, do
                         // abscissae with a small eta (1 - dD) get their own primitive
                         const double x1 = S.eta.re * P.dD1;
                         if (__builtin_amdgcn_ballot_w64(!(x1 >= 1.0)) == 0) sd1 = psinh(prim_difference(p1, pd));
-                        else sd1 = psinh(prim(x1, S.eta.im * P.dD1, S.sct, S.salt));
+                        else sd1 = psinh(prim(x1, S.eta.im * P.dD1, S.sc));
                     }
                     const cplx udp = cmul(z2 ? sd1 : csub(sd1, S.ff2), S.inv_she);
                     S.top3 = cmul(udp, S.th);
@@ -328,7 +301,7 @@ UCF_DEV cplx fast_hantush_z(const ucf_dev_params& P, const fast_common& S, doubl
     const bool need_chz = (lay == 1) || !z1 || (FAMILY == 2 && S.any_small) || FAMILY == 4;
     cplx chz = cmake(1.0, 0.0);
     fprim pz;
-    if (need_chz) { pz = prim(S.eta.re * zD, S.eta.im * zD, S.sct, S.salt); chz = pcosh(pz); }
+    if (need_chz) { pz = prim(S.eta.re * zD, S.eta.im * zD, S.sc); chz = pcosh(pz); }
     *chz_out = chz;
     cplx udp;
     if (lay == 1) {
@@ -339,14 +312,12 @@ UCF_DEV cplx fast_hantush_z(const ucf_dev_params& P, const fast_common& S, doubl
         fprim p1z;
         if (z2 && FAMILY == 2 && S.any_large) {                  // only exp(eta (zD - 1)) is wanted
             const double c = 1.0 - zD;
-            *exz_out = expneg_direct(S.eta.re * c, S.eta.im * c, S.sct, S.salt);
+            *exz_out = expneg_direct(S.eta.re * c, S.eta.im * c, S.sc);
         }
         if (need_1z) {
-#ifndef UCF_NO_PRIM_DIFFERENCE
             if (need_chz && S.have_p1 && zD >= 0.0 && zD <= 1.0) p1z = prim_difference(S.p1, pz);     // eta (1 - zD)
             else
-#endif
-            { const double c = 1.0 - zD; p1z = prim(S.eta.re * c, S.eta.im * c, S.sct, S.salt); }
+            { const double c = 1.0 - zD; p1z = prim(S.eta.re * c, S.eta.im * c, S.sc); }
         }
         if (!z2 && FAMILY == 2 && S.any_large) *exz_out = pexpneg(p1z);                         // exp(eta*(zD-1))
         cplx f2c = cmake(0.0, 0.0);
@@ -363,8 +334,8 @@ UCF_DEV cplx fast_hantush_z(const ucf_dev_params& P, const fast_common& S, doubl
             // the large parts cancel analytically:
             //   (g1 - g2) sinh(eta) = sinh(eta (2 - zD - dD))/2 + sinh(eta (zD - dD))/2 - sinh(eta lD1) cosh(eta (1 - zD))
             const double ca = 2.0 - zD - P.dD, cb = zD - P.dD;
-            const cplx sa = psinh(prim(S.eta.re * ca, S.eta.im * ca, S.sct, S.salt));
-            const cplx sb = psinh(prim(S.eta.re * cb, S.eta.im * cb, S.sct, S.salt));
+            const cplx sa = psinh(prim(S.eta.re * ca, S.eta.im * ca, S.sc));
+            const cplx sb = psinh(prim(S.eta.re * cb, S.eta.im * cb, S.sc));
             // (explicit FMAs: the same bits in every instantiation of the kernel)
             const cplx num = cmake(__builtin_fma(0.5, sa.re + sb.re, -f2c.re), __builtin_fma(0.5, sa.im + sb.im, -f2c.im));
             udp = cmul(num, S.inv_she);
@@ -388,11 +359,11 @@ UCF_DEV cplx fast_sample_z(const ucf_dev_params& P, const fast_common& S, int iz
     cplx u;
     if (P.model == 4) {
         u = S.th;
-        if (S.any_small) chz = pcosh(prim(S.eta.re * zD, S.eta.im * zD, S.sct, S.salt));
-        if (S.any_large) { const double c = 1.0 - zD; exz = expneg_direct(S.eta.re * c, S.eta.im * c, S.sct, S.salt); }
+        if (S.any_small) chz = pcosh(prim(S.eta.re * zD, S.eta.im * zD, S.sc));
+        if (S.any_large) { const double c = 1.0 - zD; exz = expneg_direct(S.eta.re * c, S.eta.im * c, S.sc); }
     } else {
         u = fast_hantush_z<2, FOLD, LAY3>(P, S, zD, lay, &chz, &exz);
-        if (S.any_large && lay == 1) { const double c = 1.0 - zD; exz = expneg_direct(S.eta.re * c, S.eta.im * c, S.sct, S.salt); }
+        if (S.any_large && lay == 1) { const double c = 1.0 - zD; exz = expneg_direct(S.eta.re * c, S.eta.im * c, S.sc); }
     }
     const cplx top = (!FOLD && LAY3 && P.model != 4 && lay == 3) ? S.top3 : S.top;
     if (S.small_eta) return csub(u, cmul(cmul(top, chz), S.inv_den));                           // :85-87

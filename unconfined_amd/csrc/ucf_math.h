@@ -101,9 +101,6 @@ UCF_DEV double fast_rcp(double x)
 // slot, so the moves doubled the cost of every polynomial); s_mov_b32 runs on the scalar unit instead.
 UCF_DEV double fmak(double a, double b, double c)
 {
-#ifdef UCF_NO_SGPR_CONSTANTS
-    return __builtin_fma(a, b, c);
-#endif
     double o;
     asm("v_fma_f64 %0, %1, %2, %3" : "=v"(o) : "v"(a), "v"(b), "s"(c));
     return o;
@@ -132,11 +129,7 @@ UCF_DEV double sgpr_const_here(int salt)
     asm("s_mov_b32 %0, %1 ; constant kept local (%2)" : "=s"(hi) : "n"((unsigned)(BITS >> 32)), "s"(salt));
     return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
-#ifdef UCF_NO_LOCAL_CONSTANTS
-#define UCF_KHERE(c, salt) (c)
-#else
 #define UCF_KHERE(c, salt) sgpr_const_here<__builtin_bit_cast(unsigned long long, (double)(c))>(salt)
-#endif
 // g = sqrt(x) and h = 1/(2 sqrt(x)) together, 1e-290 < x < 1e290 (no scaling): v_rsq_f64 estimate and two
 // coupled Newton steps on (g, h), then one correction of g.  g < 1 ulp, h ~ 1 ulp.
 UCF_DEV void sqrt_hrsqrt(double x, double* g_out, double* h_out)
@@ -152,6 +145,18 @@ UCF_DEV void sqrt_hrsqrt(double x, double* g_out, double* h_out)
     const double d = __builtin_fma(-g, g, x);
     *g_out = __builtin_fma(d, h, g);
     *h_out = h;
+}
+// sqrt(x) alone, same range: one coupled step takes the 2^-23 estimate to 2^-45 in g AND h (their errors are the same
+// to first order, which is what makes the coupled step quadratic), the correction squares that again for g.  < 1 ulp.
+UCF_DEV double sqrt_only(double x)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    const double d = __builtin_fma(-g, g, x);
+    return __builtin_fma(d, h, g);
 }
 #endif
 
@@ -246,27 +251,91 @@ UCF_DEV void sincos_medium_(double x, double* sn, double* cs)
 //     results keep their relative accuracy next to the zeros of sin and cos: 0 + (1 * sin y + 0).
 // Error < 1.5 ulp (table entry 0.5, correction 0.5 ulp of a term <= 0.0123, final addition 0.5).
 #define UCF_SC_N 256
-// (salt: any wave-uniform value that changes per loop iteration, see sgpr_const_here)
-UCF_DEV void sincos_tab_(double x, const double2* __restrict__ tab, double* sn, double* cs, int salt)
+// What a fast evaluator needs for its sin/cos: the table, a wave-uniform value that changes per loop iteration (`salt`,
+// see sgpr_const_here) and three constants held in VGPRs.  A VALU instruction of gfx9 reads at most ONE scalar operand:
+// x * (128/pi) + MAGIC and the leading Horner steps c7 z + c5 have two constants each, and the compiler's way out was to
+// copy one of them into a VGPR pair in place (two v_mov_b32 each: 5-6 of the 26 VALU instructions of every sin/cos).
+// The three constants below live in VGPRs for the whole kernel instead (opaque to the compiler, so that it does not
+// rematerialise them with the same moves).
+struct sc_ctx {
+    const double2* tab;
+    int salt;
+    int kv;                     // how many of the constants below are kept in VGPRs: 0, 1 (magic) or 4 (all); compile-time
+    double magic, s7, c6, e5;   // after inlining (the kernel sets it from its template arguments)
+};
+#define UCF_MAGIC 6755399441055744.0                                           /* 1.5 * 2^52 */
+UCF_DEV void sc_ctx_init(sc_ctx& C, const double2* tab, int kv)
 {
+    C.tab = tab;
+    C.salt = 0;
+    C.kv = kv;
+    C.magic = UCF_MAGIC;
+    C.s7 = -1.98412698412698412698e-04;
+    C.c6 = -1.38888888888888888889e-03;
+    C.e5 = 1.0 / 120.0;
+    if (kv >= 1) asm volatile("" : "+v"(C.magic));
+    if (kv >= 4) asm volatile("" : "+v"(C.s7), "+v"(C.c6), "+v"(C.e5));
+}
+// a*C + b and a*b + C: C in an SGPR pair, the other two in VGPRs
+UCF_DEV double fma_vsv(double a, double c, double b)
+{
+    double o;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(o) : "v"(a), "s"(c), "v"(b));
+    return o;
+}
+// t = x * c + MAGIC (c a constant in an SGPR pair) and fn = t - MAGIC = rint(x c); the integer is in the low mantissa bits
+// of t.  Without the VGPR copy of MAGIC: product and sum on their own (the double rounding can only move a tie).
+#define UCF_SC_MAGIC_ADD(t, fn, x, c, C, salt)                                                           \
+    double t, fn;                                                                                        \
+    if ((C).kv >= 1) { t = fma_vsv(x, c, (C).magic); fn = t - (C).magic; }                               \
+    else { t = addk(mulk(x, c), UCF_KHERE(UCF_MAGIC, salt)); fn = addk(t, UCF_KHERE(-UCF_MAGIC, salt)); }
+// first Horner step z * a + b of two constants
+#define UCF_SC_LEAD(z, av, a, b, C, salt) (((C).kv >= 4) ? fmak(z, av, UCF_KHERE(b, salt)) : addk(mulk(z, UCF_KHERE(a, salt)), UCF_KHERE(b, salt)))
+
+UCF_DEV void sincos_tab_(double x, const sc_ctx& C, double* sn, double* cs)
+{
+    const int salt = C.salt;
 #define K(c) UCF_KHERE(c, salt)
-    const double MAGIC = 6755399441055744.0;                                   // 1.5 * 2^52
-    const double t = fmak(x, K(4.07436654315252059568e+01), MAGIC);            // x * (128/pi) + magic
-    const double fn = t - MAGIC;
+    UCF_SC_MAGIC_ADD(t, fn, x, K(4.07436654315252059568e+01), C, salt)         // x * (128/pi)
     const int k = __double2loint(t) & (UCF_SC_N - 1);
     const double r = __builtin_fma(-fn, 2.45436926052207127214e-02, x);        // pio2_1 / 64: exact
     const double y = __builtin_fma(-fn, 9.49546954141592538956e-13, r);        // pio2_1t / 64
-    const double2 T = tab[k];                                                  // (sin, cos)(k pi / 128)
+    const double2 T = C.tab[k];                                                // (sin, cos)(k pi / 128)
     const double z = y * y;
     // sin y - y = y z (s3 + z (s5 + z s7));  cos y - 1 = z (c2 + z (c4 + z c6))      (Taylor: |y| <= 0.0123 leaves
     // relative 2e-21 in sin, absolute 1e-20 in cos)
-    const double ps = fmak(z, fmak(z, K(-1.98412698412698412698e-04), K(8.33333333333333333333e-03)), K(-1.66666666666666666667e-01));
-    const double pc = fmak(z, fmak(z, K(-1.38888888888888888889e-03), K(4.16666666666666666667e-02)), K(-0.5));
+    const double ps = fmak(z, UCF_SC_LEAD(z, C.s7, -1.98412698412698412698e-04, 8.33333333333333333333e-03, C, salt), K(-1.66666666666666666667e-01));
+    const double pc = fmak(z, UCF_SC_LEAD(z, C.c6, -1.38888888888888888889e-03, 4.16666666666666666667e-02, C, salt), K(-0.5));
 #undef K
     const double sy = __builtin_fma(y * z, ps, y);
     const double cm1 = z * pc;
     *sn = T.x + __builtin_fma(T.x, cm1, T.y * sy);
     *cs = T.y + __builtin_fma(T.y, cm1, -(T.x * sy));
+}
+
+// exp(x), |x| <= 709, from a table in LDS behind the sin/cos table: x = (128 e + j) ln2/128 + r, |r| <= ln2/256 = 0.0027,
+// exp(x) = 2^e * T[j] * (1 + r + r^2/2 + ... + r^5/120), T[j] = 2^(j/128) as (hi, lo) (remainder r^6/720 = 5e-19).
+// k = 128 e + j by the magic-number addition as in sincos_tab_ (two's complement in the low mantissa bits: the arithmetic
+// shift and the mask split a negative k correctly); ln2/128 = L1 + L2 with a 32-bit L1: k L1 is exact for |k| < 2^21.
+// 15-17 VALU instructions against 18 of the table-free form, and 3 coefficients instead of 12.  The result is
+// hi + (hi p + lo): one rounding of a term <= 0.003 hi and the final addition, < 0.6 ulp (a one-word table, with its own
+// half ulp per entry, doubled the noise that the ill-conditioned fixtures amplify: tools/dbg_truth.py c4_malama_partpen).
+#define UCF_EX_N 128
+UCF_DEV double exp_tab_(double x, const sc_ctx& C)
+{
+    const int salt = C.salt;
+#define K(c) UCF_KHERE(c, salt)
+    UCF_SC_MAGIC_ADD(t, fn, x, K(184.6649652337873161420704), C, salt)         // x * (128/ln2)
+    const int k = __double2loint(t);
+    double r = __builtin_fma(-fn, 0x1.62e42feep-8, x);                         // exact
+    r = __builtin_fma(-fn, 1.4907929134926466e-12, r);
+    const double2 T = C.tab[UCF_SC_N + (k & (UCF_EX_N - 1))];
+    double q = UCF_SC_LEAD(r, C.e5, 1.0 / 120.0, 1.0 / 24.0, C, salt);
+    q = fmak(q, r, K(1.0 / 6.0));
+#undef K
+    q = __builtin_fma(q, r, 0.5);
+    const double p = __builtin_fma(r * r, q, r);
+    return ldexp(T.x + __builtin_fma(T.x, p, T.y), k >> 7);
 }
 
 UCF_DEV void sincos_(double x, double* sn, double* cs)

@@ -27,6 +27,7 @@ struct ucf_dev_params {
     // fast flavour: hoisted reciprocals, plan-level exact folds, validity bound of the fast evaluation
     double inv_kappa, inv_bD, fast_eta_max, fast_im_max;
     int fold_dD, fold_lD1, share_g1top, _pad2;
+    double g1_delta;       // (dD1 - 1) + dD, exact: the argument of cosh(eta (dD1 - 1)) is -(dD - g1_delta) (share_g1top = 2)
     // Hantush with wellbore storage (:204-301): rDw, CDw (:250), tDb (:253)
     double hs_rDw, hs_CDw, hs_tDb;
     // Mishra/Neuman (Malama form, :404-442): host-evaluated scalar prefactors
@@ -43,9 +44,10 @@ struct ucf_dev_params {
     const double* j0z;     // [nj0z]
     const double* fd_e;    // [order]  exp(-beta1*(j-1)*h)
     const double* sched;   // timeType = -n: [n] start times | [n] rate increments | final time | sum of increments
-    const double* sc_tab;  // [UCF_SC_N = 256] x (sin, cos)(k pi / 128): copied into LDS by the fast flavour's kernels (sincos_tab_)
+    const double* sc_tab;  // [256] x (sin, cos)(k pi / 128) | [128] x (hi, lo) of 2^(j/128): copied into LDS by the fast flavour's kernels
+                           // (sincos_tab_, exp_tab_)
 };
-#define UCF_SC_ENTRIES 256
+#define UCF_SC_ENTRIES (256 + 128)   /* 16-byte units of that table */
 #define UCF_IWPB 4             /* waves per workgroup of integrate_kernel: they share the sin/cos table in LDS */
 
 // HIP events around the kernels of the last lane = time grid call issued through a workspace (measurement only):

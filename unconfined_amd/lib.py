@@ -32,7 +32,7 @@ EXPORTS = [
     "ucf_drawdown_batch", "ucf_drawdown_batch_device", "ucf_drawdown_grid", "ucf_drawdown_grid_device",
     "ucf_drawdown_multi", "ucf_screen_average",
     "ucf_eval_samples", "ucf_pvalues", "ucf_dehoog", "ucf_wynn_epsilon", "ucf_extraptozero", "ucf_bessel_k01",
-    "ucf_fp64_fma_peak", "ucf_sincos_table",
+    "ucf_fp64_fma_peak", "ucf_sincos_table", "ucf_exp2_table",
 ]
 
 
@@ -111,6 +111,7 @@ def load() -> C.CDLL:
     lib.ucf_bessel_k01.argtypes = [C.c_int, _dp, _dp, _ip]
     lib.ucf_fp64_fma_peak.argtypes = [C.POINTER(C.c_double)]
     lib.ucf_sincos_table.argtypes = [C.POINTER(C.c_double)]
+    lib.ucf_exp2_table.argtypes = [C.POINTER(C.c_double)]
     _lib = lib
     return lib
 
