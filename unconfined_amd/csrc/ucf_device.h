@@ -299,18 +299,21 @@ UCF_DEV cplx hantush_z(const ucf_dev_params& P, const sample_common& S, double z
 // Scaled by c >= |b_i| per lane so that nothing over- or underflows (beta_i = b_i / c has modulus <= 1, K / c^2 <= 1/4);
 // the recurrence runs in the direction in which its dominant solution grows, i.e. stably.
 // b_i = bmid - B1 e_i (i < n), b_n = b_i + invhsq - b3h  (:501-502).
-UCF_DEV cplx fd_inverse_B2(const ucf_dev_params& P, cplx B1, double bmid, double invhsq, double b3h, double K)
+// With K > 0 the substitution N_i = K^((n+1-i)/2) M_i makes the second coefficient -1: M_i = (b_i / sqrt K) M_{i+1} - M_{i+2},
+// 6 instructions per node (the K-term folds into the inner fma), 1 / B_2 = M_3 / (sqrt(K) M_2).  |M_i| <= (g + 1)^n with
+// g >= |b_i| / sqrt K: taken when (g + 1)^n < 2^500 in every lane of the wave (|M|^2 is formed at the end); the per-lane
+// scaled form otherwise.
+template <bool UNIT>
+UCF_DEV cplx fd_chain(const ucf_dev_params& P, cplx B1c, double bmc, double bn_extra, double k2, cplx* N2_out)
 {
     const int n = P.order;
-    const double emax = fmax(P.fd_e[0], P.fd_e[n - 1]);
-    const double ic = fast_rcp(fabs(bmid) + fabs(invhsq - b3h) + (fabs(B1.re) + fabs(B1.im)) * emax);      // 1 / c
-    const double bmc = bmid * ic, k2 = -(K * ic) * ic;
-    const cplx B1c = cmake(-(B1.re * ic), -(B1.im * ic));
     cplx N2 = cmake(1.0, 0.0);                                                                       // N_{n+1}
-    cplx N1 = cmake(__builtin_fma(B1c.re, P.fd_e[n - 1], __builtin_fma(invhsq - b3h, ic, bmc)), B1c.im * P.fd_e[n - 1]);   // N_n = b_n / c
-    // one node: N_i = beta_i N_{i+1} + k2 N_{i+2}, beta_i = b_i / c = (bmc + B1c.re e_i, B1c.im e_i)          (:501)
+    cplx N1 = cmake(__builtin_fma(B1c.re, P.fd_e[n - 1], bmc + bn_extra), B1c.im * P.fd_e[n - 1]);   // N_n = b_n (scaled)
+    // one node: N_i = beta_i N_{i+1} + k2 N_{i+2}, beta_i = scaled b_i = (bmc + B1c.re e_i, B1c.im e_i)            (:501)
     auto node = [&](double e, cplx Na, cplx Nb) {
         const double br = __builtin_fma(B1c.re, e, bmc), bi = B1c.im * e;
+        if (UNIT) return cmake(__builtin_fma(br, Na.re, __builtin_fma(-bi, Na.im, -Nb.re)),
+                               __builtin_fma(br, Na.im, __builtin_fma(bi, Na.re, -Nb.im)));
         return cmake(__builtin_fma(br, Na.re, __builtin_fma(-bi, Na.im, k2 * Nb.re)),
                      __builtin_fma(br, Na.im, __builtin_fma(bi, Na.re, k2 * Nb.im)));
     };
@@ -329,8 +332,27 @@ UCF_DEV cplx fd_inverse_B2(const ucf_dev_params& P, cplx B1, double bmid, double
         N2 = N1;
         N1 = N0;
     }
-    // B_2 = c N_2 / N_3  ->  1 / B_2 = N_3 / (c N_2) = N_3 conj(N_2) / (c |N_2|^2)
-    const double r = fast_rcp(N1.re * N1.re + N1.im * N1.im) * ic;
+    *N2_out = N2;
+    return N1;
+}
+UCF_DEV cplx fd_inverse_B2(const ucf_dev_params& P, cplx B1, double bmid, double invhsq, double b3h, double K)
+{
+    const int n = P.order;
+    const double emax = fmax(P.fd_e[0], P.fd_e[n - 1]);
+    const double bsum = fabs(bmid) + fabs(invhsq - b3h) + (fabs(B1.re) + fabs(B1.im)) * emax;        // >= |b_i|
+    cplx N1, N2;
+    double r;
+    if (P.fd_isk > 0.0 && __builtin_amdgcn_ballot_w64(!(bsum * P.fd_isk < P.fd_gmax)) == 0) {
+        const double s = P.fd_isk;
+        N1 = fd_chain<true>(P, cmake(-(B1.re * s), -(B1.im * s)), bmid * s, (invhsq - b3h) * s, -1.0, &N2);
+        // 1 / B_2 = M_3 / (sqrt(K) M_2) = M_3 conj(M_2) / (sqrt(K) |M_2|^2)
+        r = fast_rcp(N1.re * N1.re + N1.im * N1.im) * s;
+    } else {
+        const double ic = fast_rcp(bsum);                                                             // 1 / c
+        N1 = fd_chain<false>(P, cmake(-(B1.re * ic), -(B1.im * ic)), bmid * ic, (invhsq - b3h) * ic, -(K * ic) * ic, &N2);
+        // B_2 = c N_2 / N_3  ->  1 / B_2 = N_3 / (c N_2) = N_3 conj(N_2) / (c |N_2|^2)
+        r = fast_rcp(N1.re * N1.re + N1.im * N1.im) * ic;
+    }
     return cmake((N2.re * N1.re + N2.im * N1.im) * r, (N2.im * N1.re - N2.re * N1.im) * r);
 }
 #endif

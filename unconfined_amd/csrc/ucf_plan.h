@@ -34,6 +34,7 @@ struct ucf_dev_params {
     double mn_vartheta, mn_u0;
     // Mishra/Neuman FD (:444-544)
     double fd_h, fd_invhsq, fd_beta0, fd_beta3, fd_expmb2;   // exp(-beta2)
+    double fd_isk, fd_gmax;                   // 1/sqrt(K), K = (1/h^2 - beta3/h)/h^2 (0 if K <= 0); 2^(500/order) - 1 (fd_inverse_B2)
     double hv[UCF_MAX_R];                     // Richardson spacings (driver.f90:91)
     double zD[UCF_MAX_NZ];
     int zLay[UCF_MAX_NZ];
