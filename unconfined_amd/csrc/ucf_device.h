@@ -637,12 +637,30 @@ UCF_DEV double dehoog_wave(cplx f, int M, double alpha, double logtol, double t,
 }
 
 // dehoog_wave in two halves, for kernels that invert many vectors per wave (dehoog_tiles_kernel):
-//   dehoog_qd_wave   the quotient-difference rhombus (:80-101), cooperative as above; lane k keeps the
-//                    continued-fraction coefficient d(k) instead of every lane running the recurrence on broadcasts;
+//   dehoog_qd_wave   the quotient-difference rhombus (:80-101), cooperative as above; the continued-fraction
+//                    coefficients d(k) go to an LDS column instead of every lane running the recurrence on broadcasts;
 //   dehoog_cf_lane   the A/B recurrence, improved remainder and scaling (:105-129) of ONE vector by ONE lane,
 //                    coefficients read from an LDS column -- 2T lanes finish 2T vectors at once.
-// Operation for operation the arithmetic of dehoog_wave: same bits.
-UCF_DEV cplx dehoog_qd_wave(cplx f, int M, int lane, ucf_stats* st, bool* zero)
+// Operation for operation the arithmetic of dehoog_wave: same bits (faithful flavour; the fast one takes the unscaled
+// quotient below where it can).
+// q(i,r+1) = q(i+1,r) e(i+1,r) / e(i,r) (:93).  Fast flavour: product times conj(e)/|e|^2 without the exponent scaling of
+// __divdc3 when every lane's |e| is far from over- and underflow of its square (the lanes outside the rhombus hold 1).
+UCF_DEV cplx qd_quotient(cplx qn, cplx enn, cplx enew)
+{
+#if UCF_FAST
+    const double m = fmax(fabs(enew.re), fabs(enew.im));
+    if (__builtin_amdgcn_ballot_w64(!(m < 1.0e150 && m > 1.0e-150)) == 0) {
+        const double r = fast_rcp(__builtin_fma(enew.re, enew.re, enew.im * enew.im));
+        const cplx num = cmul(qn, enn);
+        return cmake((num.re * enew.re + num.im * enew.im) * r, (num.im * enew.re - num.re * enew.im) * r);
+    }
+#endif
+    return cdiv(cmul(qn, enn), enew);
+}
+// The continued-fraction coefficients go straight to column `dcol` of an LDS tile (d(k) in row k, `pitch` apart): lane 0,
+// which holds q(0,r) and e(0,r), stores d(2r-1) and d(2r) as they appear -- no broadcast, no per-lane selects.  e(i+1,r)
+// of one step is the shifted e of the next: one shift less per step.
+UCF_DEV void dehoog_qd_wave(cplx f, int M, int lane, ucf_stats* st, bool* zero, lds_c* dcol, int pitch)
 {
     const int n2 = 2 * M;
     const bool act = lane <= n2;
@@ -652,35 +670,33 @@ UCF_DEV cplx dehoog_qd_wave(cplx f, int M, int lane, ucf_stats* st, bool* zero)
     *zero = !(mx > UCF_DBL_MIN);                         // :69,139
     if (*zero) {
         if (st) stat_add(&st->zero_vectors, lane == 0);
-        return cmake(0.0, 0.0);
+        return;
     }
     const bool nanp = act && (d_isnan(f.re) || d_isnan(f.im));
     if (st) stat_add(&st->nan_scrubbed, nanp);
     cplx ff = (nanp || !act) ? cmake(act ? 0.0 : 1.0, 0.0) : f;                                 // :71-74
     const cplx ff0 = bcast0(ff);
     const cplx d0 = cdivr(ff0, 2.0);                                                            // :98
-    cplx dmine = d0;                                     // lane 0 keeps d(0); the others are overwritten below
+    if (lane == 0) dcol[0] = make_double2(d0.re, d0.im);
     cplx fnext = shfl_down1(ff);
     cplx q = (lane == 0) ? cdiv(fnext, d0) : cdiv(fnext, ff);                                   // :81-82  q(i,1)
     if (lane > n2 - 1) q = cmake(1.0, 0.0);
-    cplx e = cmake(0.0, 0.0);                                                                   // :80     e(i,0)
+    cplx en = cmake(0.0, 0.0);                                                                  // :80     e(i+1,0)
     for (int r = 1; r <= M; r++) {                                                              // :85-95
         const cplx qn = shfl_down1(q);
-        const cplx en = shfl_down1(e);
         cplx enew = cadd(csub(qn, q), en);
         if (lane > 2 * (M - r)) enew = cmake(1.0, 0.0);      // outside the rhombus: keep lanes benign
-        const cplx dq = cneg(bcast0(q));                     // d(2r-1) = -q(0,r)                :100
-        const cplx de = cneg(bcast0(enew));                  // d(2r)   = -e(0,r)                :101
-        if (lane == 2 * r - 1) dmine = dq;
-        if (lane == 2 * r) dmine = de;
+        if (lane == 0) {
+            dcol[(size_t)(2 * r - 1) * pitch] = make_double2(-q.re, -q.im);                     // d(2r-1) = -q(0,r)   :100
+            dcol[(size_t)(2 * r) * pitch] = make_double2(-enew.re, -enew.im);                   // d(2r)   = -e(0,r)   :101
+        }
         if (r < M) {
             const cplx enn = shfl_down1(enew);
-            q = cdiv(cmul(qn, enn), enew);                                                      // :93
+            q = qd_quotient(qn, enn, enew);                                                     // :93
             if (lane > 2 * (M - r - 1) + 1) q = cmake(1.0, 0.0);
-            e = enew;
+            en = enn;
         }
     }
-    return dmine;
 }
 
 UCF_DEV double dehoog_cf_lane(const lds_c* dcol, int pitch, int M, double alpha, double logtol, double t, double tee)
@@ -1595,12 +1611,8 @@ dehoog_tiles_kernel(const ucf_dev_params P, int nt, int nr, int ir0, int nrc, co
                     if (lane < np) { const lds_c v = lds[lane * pitch + tt]; tl = cmake(v.x, v.y); }
                     const cplx p = cmake(sigma, UCF_PI * lane / tee);
                     bool z0, z1;
-                    const cplx dh_ = dehoog_qd_wave(tl, P.M, lane, st, &z0);
-                    const cplx dd_ = dehoog_qd_wave(cmul(tl, p), P.M, lane, st, &z1);
-                    if (lane < np) {
-                        lds[lane * pitch + tt] = make_double2(dh_.re, dh_.im);
-                        tileB[lane * pitch + tt] = make_double2(dd_.re, dd_.im);
-                    }
+                    dehoog_qd_wave(tl, P.M, lane, st, &z0, lds + tt, pitch);          // (column tt of the tile is in `tl` by now)
+                    dehoog_qd_wave(cmul(tl, p), P.M, lane, st, &z1, tileB + tt, pitch);
                     if (lane == 0) { zflag[2 * tt] = z0; zflag[2 * tt + 1] = z1; }
                 }
                 __syncthreads();
