@@ -242,6 +242,12 @@ int ucf_drawdown_grid_multi(ucf_plan* const* plans, int ngpu, int nt, const doub
                             const double* rD, int nz, const double* zD, const int* zLay, double* h, double* dh,
                             ucf_stats* stats);
 
+/* The point-list counterpart (ucf_drawdown_batch_multi): block g of the list -- ucf_shard_rows over
+ * the npts points -- runs on plans[g]'s device, one host thread per device, each through ucf_drawdown_batch (which
+ * orders its block by radius); results land in the caller's order in h, dh [npts][nz].  ngpu = 1 is ucf_drawdown_batch. */
+int ucf_drawdown_batch_multi(ucf_plan* const* plans, int ngpu, int npts, const double* tD, const double* rD, const int* sv,
+                             int nz, const double* zD, const int* zLay, double* h, double* dh, ucf_stats* stats);
+
 /* Parameter-batched evaluation for inversion / fitting (the tool's real use,
  * reference README.md:45-56): the SAME observation points -- dimensional times t[npts], radii r[npts],
  * depths z[nz] (z up from the aquifer base) -- under nplans parameter sets.  Each plan

@@ -185,6 +185,32 @@ def test_grid_multi_equals_single(engine, name):
     assert np.array_equal(h, h0, equal_nan=True) and np.array_equal(d, d0, equal_nan=True)
 
 
+def test_batch_multi_equals_single(engine):
+    """ucf_drawdown_batch_multi: a point list cut into blocks (ucf_shard_rows over the points) over several plans, one host
+    thread per plan -- on this box all on the one GPU -- gives the single-plan result bit for bit in the faithful flavour
+    (values, NaN pattern and in-band rule counts); the fast flavour, whose waves leave the fast evaluators together, to
+    rounding (a block boundary regroups the lanes)"""
+    dk, ts, P = load_deck("neuman74_partpen")
+    single = engine.Plan(P, mode="faithful")
+    zD = np.array([0.2, 0.6, 0.97]); zl = single.zlay(zD)
+    rng = np.random.default_rng(7)
+    for nplans, npts in ((2, 301), (3, 64), (4, 3)):
+        tD = 10.0 ** rng.uniform(-2.0, 3.0, npts); rD = 10.0 ** rng.uniform(-1.0, 1.0, npts)
+        sv = single.split_vector(tD)
+        h0, d0, st0 = single.drawdown(tD, rD, sv, zD, zl, with_stats=True)
+        plans = [engine.Plan(P, mode="faithful") for _ in range(nplans)]
+        h, d, st = engine.drawdown_batch_multi(plans, tD, rD, sv, zD, zl, with_stats=True)
+        assert np.array_equal(h, h0, equal_nan=True) and np.array_equal(d, d0, equal_nan=True), (nplans, npts)
+        assert st == st0
+    fast = engine.Plan(P, mode="fast")
+    tD = 10.0 ** rng.uniform(-2.0, 3.0, 700); rD = 10.0 ** rng.uniform(-1.0, 1.0, 700)
+    sv = fast.split_vector(tD)
+    h0, d0 = fast.drawdown(tD, rD, sv, zD, zl)
+    h, d = engine.drawdown_batch_multi([engine.Plan(P, mode="fast") for _ in range(3)], tD, rD, sv, zD, zl)
+    assert np.array_equal(np.isnan(h), np.isnan(h0))
+    assert np.nanmax(np.abs(h - h0) / np.maximum(np.abs(h0), 1e-3)) < 1e-9 and np.nanmax(np.abs(d - d0) / np.maximum(np.abs(d0), 1e-3)) < 1e-7
+
+
 def test_shard_device_entry_fills_its_rows_in_place(engine):
     """ucf_drawdown_grid_shard_device: rank g writes rows shard_rows(g) of the full-size arrays and nothing else; all
     ranks together give the whole sweep"""

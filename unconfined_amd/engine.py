@@ -232,6 +232,21 @@ def drawdown_grid_multi(plans, tD, sv, rD, zD, zLay, with_stats: bool = False):
     return h, dh
 
 
+def drawdown_batch_multi(plans, tD, rD, sv, zD, zLay, with_stats: bool = False):
+    """one point list on len(plans) devices driven by this process (ucf_drawdown_batch_multi): h, dh [npts, nz]"""
+    lib = _libmod.load()
+    tD, rD, sv, zD, zLay = _f64(tD), _f64(rD), _i32(sv), _f64(zD), _i32(zLay)
+    npts, nz = len(tD), len(zD)
+    arr = (C.c_void_p * len(plans))(*[p._h for p in plans])
+    h = np.zeros((npts, nz))
+    dh = np.zeros((npts, nz))
+    st = UcfStats()
+    _libmod.check(lib.ucf_drawdown_batch_multi(arr, len(plans), npts, tD, rD, sv, nz, zD, zLay, h, dh, C.byref(st) if with_stats else None))
+    if with_stats:
+        return h, dh, {k: getattr(st, k) for k, _ in UcfStats._fields_}
+    return h, dh
+
+
 def drawdown_multi(plans, t, r, z, dimensionless: bool = False):
     """the same dimensional observation points under many parameter sets (inversion / fitting):
     h, dh of shape [nplans, npts, nz]"""

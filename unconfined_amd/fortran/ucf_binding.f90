@@ -41,7 +41,8 @@ module ucf_binding
   public :: ucf_version, ucf_last_error, ucf_plan_create, ucf_plan_destroy, ucf_plan_update, ucf_plan_derived, &
        & ucf_plan_set_mode, ucf_logspace, ucf_linspace, ucf_zlay, ucf_split_vector, &
        & ucf_drawdown_grid, ucf_drawdown_batch, ucf_screen_average, ucf_error_message, &
-       & ucf_nondimensionalise, ucf_device_count, ucf_plan_create_on, ucf_shard_rows, ucf_drawdown_grid_multi
+       & ucf_nondimensionalise, ucf_device_count, ucf_plan_create_on, ucf_shard_rows, ucf_drawdown_grid_multi, &
+       & ucf_drawdown_batch_multi
 
   interface
      function ucf_version() bind(C, name='ucf_version') result(v)
@@ -189,6 +190,19 @@ module ucf_binding
        type(ucf_stats), intent(out) :: stats
        integer(c_int) :: rc
      end function ucf_drawdown_grid_multi
+
+     ! the point-list counterpart: blocks of the list on plans(g)'s devices, h, dh [nz, npts] in Fortran order
+     function ucf_drawdown_batch_multi(plans, ngpu, npts, tD, rD, sv, nz, zD, zLay, h, dh, stats) &
+          & bind(C, name='ucf_drawdown_batch_multi') result(rc)
+       import :: c_int, c_double, c_ptr, ucf_stats
+       type(c_ptr), intent(in) :: plans(*)
+       integer(c_int), value :: ngpu, npts, nz
+       real(c_double), intent(in) :: tD(*), rD(*), zD(*)
+       integer(c_int), intent(in) :: sv(*), zLay(*)
+       real(c_double), intent(out) :: h(*), dh(*)
+       type(ucf_stats), intent(out) :: stats
+       integer(c_int) :: rc
+     end function ucf_drawdown_batch_multi
 
      function ucf_screen_average(npts, zOrd, h, havg) bind(C, name='ucf_screen_average') result(rc)
        import :: c_int, c_double

@@ -27,7 +27,7 @@ EXPORTS = [
     "ucf_plan_create", "ucf_plan_create_on", "ucf_device_count", "ucf_plan_destroy", "ucf_plan_update", "ucf_plan_derived", "ucf_nondimensionalise", "ucf_plan_j0z", "ucf_plan_tanh_sinh",
     "ucf_plan_gauss_lobatto", "ucf_plan_set_mode", "ucf_plan_set_timing", "ucf_plan_kernel_ms", "ucf_plan_kernel_times",
     "ucf_plan_reserve", "ucf_plan_alloc_count", "ucf_build_id",
-    "ucf_shard_rows", "ucf_drawdown_grid_shard_device", "ucf_drawdown_grid_multi",
+    "ucf_shard_rows", "ucf_drawdown_grid_shard_device", "ucf_drawdown_grid_multi", "ucf_drawdown_batch_multi",
     "ucf_logspace", "ucf_linspace", "ucf_zlay", "ucf_split_vector",
     "ucf_drawdown_batch", "ucf_drawdown_batch_device", "ucf_drawdown_grid", "ucf_drawdown_grid_device",
     "ucf_drawdown_multi", "ucf_screen_average",
@@ -93,6 +93,7 @@ def load() -> C.CDLL:
     lib.ucf_drawdown_grid_shard_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp, C.c_int, _dp, _ip, vp, vp, vp, vp]
     lib.ucf_drawdown_grid_multi.argtypes = [C.POINTER(vp), C.c_int, C.c_int, _dp, _ip, C.c_int, _dp, C.c_int, _dp, _ip, _dp, _dp,
                                             C.POINTER(UcfStats)]
+    lib.ucf_drawdown_batch_multi.argtypes = [C.POINTER(vp), C.c_int, C.c_int, _dp, _dp, _ip, C.c_int, _dp, _ip, _dp, _dp, C.POINTER(UcfStats)]
     lib.ucf_logspace.argtypes = [C.c_int, C.c_int, C.c_int, _dp]
     lib.ucf_linspace.argtypes = [C.c_double, C.c_double, C.c_int, _dp]
     lib.ucf_zlay.argtypes = [vp, C.c_int, _dp, _ip]
