@@ -1360,6 +1360,7 @@ integrate_kernel(const ucf_dev_params P0, int npts, int per_point, int nr, int n
 #endif
     const int lane = threadIdx.x & (UCF_WAVE - 1), wv = threadIdx.x / UCF_WAVE;
     const int nz = P0.nz, R = P0.R, nacc = P0.nacc, N = P0.N, ngl = P0.ngl;
+    __builtin_assume(nz >= 1 && R >= 1 && nacc >= 1 && ngl >= 1);     // (the launcher's business: no loop guards in the kernel)
     const int nabs = N + nacc * ngl;
     // LDS: [256] sin/cos table | per wave: [R][nz] level sums, [nz] area of the J0 interval being integrated
     {
@@ -1404,7 +1405,7 @@ integrate_kernel(const ucf_dev_params P0, int npts, int per_point, int nr, int n
             const bool ts = n < N;
             const double w = ts ? 0.0 : P.gl_w[m];
             F.sc.salt = n;
-            if (!__all(fast_eta<FAMILY>(P, LC, aa.x, F))) break;
+            if (__builtin_amdgcn_ballot_w64(!fast_eta<FAMILY>(P, LC, aa.x, F)) != 0) break;      // (every lane is live here)
             fast_common_terms<FAMILY, FOLD, LAY3>(P, LC, aa.x, need_lay1, F, need_lay3, need_lay12);
             const int n1 = n + 1;
             int tz = __builtin_ctz(n1);

@@ -127,11 +127,11 @@ struct fast_common {
     sc_ctx sc;           // sin/cos table in LDS + constants (sincos_tab_), set once per kernel; sc.salt = the loop counter
     cplx th, eta, ff1, ff2, inv_she, she, che, top, g3, inv_den, ex1;   // ex1 = exp(-eta)
     fprim p1;            // primitive of eta itself (valid when have_p1)
-    bool have_p1;
+    int have_p1;         // (wave-uniform flags are ints: a uniform bool that crosses a join is rebuilt through VALU selects)
     cplx fd_s1;          // FD: sigma(1)
     cplx top3, fd_s13;   // the same two for depths above the screen top (cancellation-free water-table value)
     bool small_eta, fd_use, fd_use3;
-    bool any_small, any_large;   // wave-uniform: some lane on the cosh/sinh form, some lane on the exponential form
+    int any_small, any_large;    // wave-uniform: some lane on the cosh/sinh form, some lane on the exponential form
 };
 
 // Every fast sample is linear in theis(a, p) = 2/(p + a^2) and, for the Hantush-based models, carries the factor
@@ -163,7 +163,8 @@ UCF_DEV bool fast_eta(const ucf_dev_params& P, const lane_consts& L, double a, f
         sqrt_hrsqrt(0.5 * (d + qr), &r, &hr);
         S.eta = cmake(r, qi * hr);
     }
-    return (S.eta.re <= P.fast_eta_max) && (q.re > 0.0) && (fabs(S.eta.im) < P.fast_im_max);
+    // (three compares and two scalar ANDs; the short-circuit form rebuilt the flag through a select)
+    return (bool)((int)(S.eta.re <= P.fast_eta_max) & (int)(q.re > 0.0) & (int)(fabs(S.eta.im) < P.fast_im_max));
 }
 
 // z-independent part (after fast_eta said yes for every lane of the wave)
@@ -182,10 +183,10 @@ UCF_DEV void fast_common_terms(const ucf_dev_params& P, const lane_consts& L, do
     // the water-table closure switches to its exponential form at Re(eta) >= maxexp (:84) and then needs neither
     // cosh(eta) nor sinh(eta): decide per wave what has to be evaluated at all
     S.small_eta = (FAMILY != 2) || (S.eta.re < P.maxexp);                                       // :84
-    S.any_small = (FAMILY != 2) || (__builtin_amdgcn_ballot_w64(S.small_eta) != 0);
-    S.any_large = (FAMILY == 2) && (__builtin_amdgcn_ballot_w64(!S.small_eta) != 0);
+    S.any_small = ((FAMILY != 2) || (__builtin_amdgcn_ballot_w64(S.small_eta) != 0)) ? 1 : 0;
+    S.any_large = ((FAMILY == 2) && (__builtin_amdgcn_ballot_w64(!S.small_eta) != 0)) ? 1 : 0;
     const bool need_p1 = (hantush && (!(z1 && z2) || need_lay1)) || FAMILY == 4 || (FAMILY == 2 && S.any_small);
-    S.have_p1 = need_p1 && !z2;      // kept only where fast_hantush_z derives the primitive of eta (1 - zD) from it
+    S.have_p1 = (need_p1 && !z2) ? 1 : 0;      // kept only where fast_hantush_z derives the primitive of eta (1 - zD) from it
     fprim p1;
     if (need_p1) {
         p1 = prim(S.eta.re, S.eta.im, S.sc);
