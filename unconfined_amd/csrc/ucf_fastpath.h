@@ -195,7 +195,7 @@ UCF_DEV void fast_common_terms(const ucf_dev_params& P, const lane_consts& L, do
         S.she = psinh(p1);
         S.ex1 = pexpneg(p1);
     } else {
-        S.che = S.she = S.ex1 = cmake(0.0, 0.0);
+        S.che = S.she = S.ex1 = cmake(0.0, 0.0);     // (read by lanes that do not use them: must be benign numbers)
     }
     if (hantush) {
         fprim pd;
@@ -247,10 +247,14 @@ UCF_DEV void fast_common_terms(const ucf_dev_params& P, const lane_consts& L, do
     }
     if (FAMILY == 2) {
         const cplx xi = cmul(S.eta, L.xifac);                                                   // :70-75
-        cplx one_bex = cmake(1.0, 0.0);
-        if (P.beta != 0.0) one_bex = radd(1.0, cmul(rscale(P.beta, S.eta), xi));
-        if (S.small_eta) S.inv_den = cinv_auto(cadd(cmul(one_bex, S.che), cmul(xi, S.she)));  // :86-87
-        else S.inv_den = cinv_auto(cadd(one_bex, xi));                                        // :90-91
+        if (P.beta != 0.0) {
+            const cplx one_bex = radd(1.0, cmul(rscale(P.beta, S.eta), xi));
+            if (S.small_eta) S.inv_den = cinv_auto(cadd(cmul(one_bex, S.che), cmul(xi, S.she)));  // :86-87
+            else S.inv_den = cinv_auto(cadd(one_bex, xi));                                        // :90-91
+        } else {                                                 // beta = 0 (wave-uniform): no product with (1, 0)
+            if (S.small_eta) S.inv_den = cinv_auto(cadd(S.che, cmul(xi, S.she)));
+            else S.inv_den = cinv_auto(radd(1.0, xi));
+        }
     }
     if (FAMILY == 4) {
         // Mishra/Neuman finite-difference vadose zone (:444-544): sigma(1) of the tridiagonal system by
