@@ -126,6 +126,7 @@ UCF_DEV lane_consts make_lane_consts(const ucf_dev_params& P, cplx p, cplx lt)
 struct fast_common {
     sc_ctx sc;           // sin/cos table in LDS + constants (sincos_tab_), set once per kernel; sc.salt = the loop counter
     cplx th, eta, ff1, ff2, inv_she, she, che, top, g3, inv_den, ex1;   // ex1 = exp(-eta)
+    cplx q, den;         // p + a^2; closure denominator (kept when inv_den = 1 / (q den), see fast_common_terms)
     fprim p1;            // primitive of eta itself (valid when have_p1)
     int have_p1;         // (wave-uniform flags are ints: a uniform bool that crosses a join is rebuilt through VALU selects)
     cplx fd_s1;          // FD: sigma(1)
@@ -152,6 +153,7 @@ UCF_DEV bool fast_eta(const ucf_dev_params& P, const lane_consts& L, double a, f
 {
     const double a2 = a * a;
     const cplx q = caddr(L.p, a2);
+    S.q = q;
     {
         const double r = fast_rcp(q.re * q.re + q.im * q.im);
         S.th = cmake(q.re * r, -(q.im * r));                      // HALF of theis = 2/q (:122-131): see fast_scale()
@@ -247,13 +249,22 @@ UCF_DEV void fast_common_terms(const ucf_dev_params& P, const lane_consts& L, do
     }
     if (FAMILY == 2) {
         const cplx xi = cmul(S.eta, L.xifac);                                                   // :70-75
+        cplx den;
         if (P.beta != 0.0) {
             const cplx one_bex = radd(1.0, cmul(rscale(P.beta, S.eta), xi));
-            if (S.small_eta) S.inv_den = cinv_auto(cadd(cmul(one_bex, S.che), cmul(xi, S.she)));  // :86-87
-            else S.inv_den = cinv_auto(cadd(one_bex, xi));                                        // :90-91
+            if (S.small_eta) den = cadd(cmul(one_bex, S.che), cmul(xi, S.she));                 // :86-87
+            else den = cadd(one_bex, xi);                                                       // :90-91
         } else {                                                 // beta = 0 (wave-uniform): no product with (1, 0)
-            if (S.small_eta) S.inv_den = cinv_auto(cadd(S.che, cmul(xi, S.she)));
-            else S.inv_den = cinv_auto(radd(1.0, xi));
+            if (S.small_eta) den = cadd(S.che, cmul(xi, S.she));
+            else den = radd(1.0, xi);
+        }
+        // Where the Hantush factor and the water-table value are both theis = 1/q (fully penetrating well; model 4) the
+        // sample is (1/q) (1 - f_z / den) = (den - f_z) / (q den): ONE reciprocal instead of two (and no 1/q at all)
+        if (FOLD || !hantush) {
+            S.den = den;
+            S.inv_den = cinv_auto(cmul(S.q, den));
+        } else {
+            S.inv_den = cinv_auto(den);
         }
     }
     if (FAMILY == 4) {
@@ -369,6 +380,10 @@ UCF_DEV cplx fast_sample_z(const ucf_dev_params& P, const fast_common& S, int iz
     } else {
         u = fast_hantush_z<2, FOLD, LAY3>(P, S, zD, lay, &chz, &exz);
         if (S.any_large && lay == 1) { const double c = 1.0 - zD; exz = expneg_direct(S.eta.re * c, S.eta.im * c, S.sc); }
+    }
+    if (FOLD || P.model == 4) {                                  // u = top = 1/q: (den - f_z) / (q den), fast_common_terms
+        const cplx fz = S.small_eta ? chz : exz;
+        return cmul(csub(S.den, fz), S.inv_den);
     }
     const cplx top = (!FOLD && LAY3 && P.model != 4 && lay == 3) ? S.top3 : S.top;
     if (S.small_eta) return csub(u, cmul(cmul(top, chz), S.inv_den));                           // :85-87
