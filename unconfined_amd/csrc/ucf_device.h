@@ -1075,7 +1075,7 @@ struct work_item {
     bool live;
 };
 template <int LAYOUT>
-UCF_DEV work_item decode_item(const ucf_dev_params& P, int pt, int lane, int per_point, int nr, int nt, int ir0)
+UCF_DEV work_item decode_item(const ucf_dev_params& P, int pt, int lane, int per_point, int nr, int nt, int ir0, int npts)
 {
     work_item W;
     W.plan = 0;
@@ -1110,10 +1110,14 @@ UCF_DEV work_item decode_item(const ucf_dev_params& P, int pt, int lane, int per
     } else {
         // work item = (radius of this chunk, tile of 64 times, Laplace index); m fastest so that
         // neighbouring waves share the abscissa row and the times
+        // The LAST radius of the chunk first: with radii in ascending order (the usual sweep) the far ones stay longest on
+        // the cosh/sinh form of the closure and cost up to 1.5 x the near ones -- longest items first leaves the cheap ones
+        // to fill the tail of the launch (matters for small launches: the shards of a strong-scaling run).
         const int ntiles = (nt + UCF_WAVE - 1) / UCF_WAVE;
         W.mlap = pt % P.np;
         const int tile = (pt / P.np) % ntiles;
-        W.ir = ir0 + pt / (P.np * ntiles);
+        const int per_r = P.np * ntiles;
+        W.ir = ir0 + (npts / per_r - 1 - pt / per_r);
         W.it = tile * UCF_WAVE + lane;
         W.live = W.it < nt;
         if (!W.live) W.it = nt - 1;
@@ -1251,7 +1255,7 @@ point_kernel(const ucf_dev_params P0, int npts, int per_point, int nr, int nsv, 
 
     for (int wi = blockIdx.x; wi < nloop; wi += gridDim.x) {
         const int pt = resume ? todo[1 + wi] : wi;
-        const work_item W = decode_item<LAYOUT>(P0, pt, lane, per_point, nr, nt, ir0);
+        const work_item W = decode_item<LAYOUT>(P0, pt, lane, per_point, nr, nt, ir0, npts);
         const int it = W.it, ir = W.ir, mlap = W.mlap, pidx = W.pidx;
         const ucf_dev_params& P = item_params<MULTI>(P0, Pv, (LAYOUT == 3 ? W.plan * ppp : pidx) + pbase, ppp);
         bool need_lay1 = false;
@@ -1373,7 +1377,7 @@ integrate_kernel(const ucf_dev_params P0, int npts, int per_point, int nr, int n
     lds_c* accTS = wlds;                                    // [R][nz]  level sums
     lds_c* accCur = wlds + (size_t)R * nz * UCF_WAVE;       // [nz]     area of the J0 interval being integrated
     for (int pt = blockIdx.x * UCF_IWPB + wv; pt < npts; pt += gridDim.x * UCF_IWPB) {
-        const work_item W = decode_item<LAYOUT>(P0, pt, lane, per_point, nr, nt, ir0);
+        const work_item W = decode_item<LAYOUT>(P0, pt, lane, per_point, nr, nt, ir0, npts);
         const ucf_dev_params& P = item_params<MULTI>(P0, Pv, (LAYOUT == 3 ? W.plan * ppp : W.pidx) + pbase, ppp);
         bool need_lay1 = false, need_lay3 = false, need_lay12 = false;
         for (int z = 0; z < nz; z++) { need_lay1 |= (P.zLay[z] == 1); need_lay3 |= (P.zLay[z] == 3); need_lay12 |= (P.zLay[z] != 3); }
@@ -1480,7 +1484,7 @@ integrate_generic_kernel(const ucf_dev_params P, int npts, int per_point, int nr
     bool need_lay1 = false;
     for (int z = 0; z < nz; z++) need_lay1 |= (P.zLay[z] == 1);
     for (int pt = blockIdx.x; pt < npts; pt += gridDim.x) {
-        const work_item W = decode_item<LAYOUT>(P, pt, lane, per_point, nr, nt, ir0);
+        const work_item W = decode_item<LAYOUT>(P, pt, lane, per_point, nr, nt, ir0, npts);
         const double tD = tDv[W.it], rD = rDv[W.ir];
         const int sv = (LAYOUT == 1) ? svmin : svv[W.it];
         const double2* __restrict__ row = tab + (size_t)(per_point ? W.pidx : (W.ir * nsv + (sv - svmin))) * nabs;
@@ -1549,7 +1553,7 @@ finish_kernel(const ucf_dev_params P, int npts, int per_point, int nr, int nsv, 
     lds_c* scr = lds + (size_t)R * nz * UCF_WAVE;
     for (int pt = blockIdx.x; pt < npts; pt += gridDim.x) {
         if (ndone[pt] < nabs) continue;
-        const work_item W = decode_item<LAYOUT>(P, pt, lane, per_point, nr, nt, ir0);
+        const work_item W = decode_item<LAYOUT>(P, pt, lane, per_point, nr, nt, ir0, npts);
         const double tD = tDv[W.it], rD = rDv[W.ir];
         const int sv = (LAYOUT == 1) ? svmin : svv[W.it];
         const double tee = 2.0 * tD;
