@@ -138,3 +138,19 @@ def test_device_entries_say_no_device_without_a_gpu(so):
     h = C.c_void_p()
     assert so.ucf_plan_create_on(C.byref(P), 0, C.byref(h)) == -12 and not h.value
     assert b"no CPU fallback" in so.ucf_last_error()
+
+
+def test_multi_device_entries_check_their_arguments(so):
+    """ucf_drawdown_grid_multi / ucf_drawdown_batch_multi: argument errors are reported before any device is touched"""
+    import numpy as np
+    d = np.zeros(4)
+    i = np.ones(4, np.int32)
+    dp = ip = lambda a: a                  # (lib.py declares these arguments as numpy arrays)
+    none = C.POINTER(C.c_void_p)()
+    assert so.ucf_drawdown_batch_multi(none, 2, 4, dp(d), dp(d), ip(i), 1, dp(d), ip(i), dp(d), dp(d), None) == -11
+    assert so.ucf_drawdown_grid_multi(none, 2, 2, dp(d), ip(i), 2, dp(d), 1, dp(d), ip(i), dp(d), dp(d), None) == -11
+    plans = (C.c_void_p * 2)(None, None)
+    assert so.ucf_drawdown_batch_multi(plans, 2, 4, dp(d), dp(d), ip(i), 1, dp(d), ip(i), dp(d), dp(d), None) == -11
+    assert b"plans[0]" in so.ucf_last_error()
+    assert so.ucf_drawdown_batch_multi(plans, 0, 4, dp(d), dp(d), ip(i), 1, dp(d), ip(i), dp(d), dp(d), None) == -11
+
