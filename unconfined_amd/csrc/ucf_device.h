@@ -1161,7 +1161,7 @@ UCF_DEV void finish_item(const ucf_dev_params& P, lds_c* accTS, lds_c* scr, cons
                 if (jj < nacc) {
                     const double2 v = areas[(size_t)(jj * nz + z) * UCF_WAVE + lane];
                     ser[jj] = cmake(v.x, v.y);
-                    any |= (cabs_(ser[jj]) > 0.0);                                              // :209
+                    any |= c_abs_positive(ser[jj]);                                              // :209
                 }
             }
             for (int part = 0; part < UCF_WAVE / PART; part++)
@@ -1181,7 +1181,7 @@ UCF_DEV void finish_item(const ucf_dev_params& P, lds_c* accTS, lds_c* scr, cons
                         const double2 v = areas[(size_t)(jj * nz + z) * UCF_WAVE + lane];
                         ar = cmake(v.x, v.y);
                     }
-                    any |= (cabs_(ar) > 0.0);                                                   // :209
+                    any |= c_abs_positive(ar);                                                   // :209
                     scr_st<PART>(colA, jj, lane, ar);
                 }
                 if (any) infint = wynn_lane<PART>(colA, colB, nacc, lane, &wst);

@@ -190,11 +190,24 @@ UCF_DEV cplx rdiv(double s, cplx y) { return cdiv(cmake(s, 0.0), y); }      // r
 UCF_DEV cplx cdivr(cplx x, double s) { return cdiv(x, cmake(s, 0.0)); }     // complex/real (flang -> __divdc3)
 
 UCF_DEV double cabs_(cplx z) { return hypot(z.re, z.im); }
-// utility.f90:59-64
+// utility.f90:59-64: abs(z) is neither NaN nor > huge.  Decided WITHOUT forming hypot where that is certain (same answers:
+// hypot is NaN or Inf as soon as a component is; two finite components below huge / sqrt(2) cannot overflow it; the rare
+// rest asks hypot itself) -- the series acceleration calls this once per term, ~30 instructions each through hypot.
 UCF_DEV bool c_is_finite(cplx z)
 {
-    double m = cabs_(z);
-    return !(d_isnan(m) || m > 1.7976931348623157e308);
+    if (d_isnan(z.re) || d_isnan(z.im)) return false;             // hypot: NaN, or Inf if the other component is infinite
+    const double m = fmax(fabs(z.re), fabs(z.im));
+    if (__builtin_expect(m < 1.2e308, 1)) return true;            // (an infinite component lands below)
+    const double h = cabs_(z);
+    return !(h > 1.7976931348623157e308);
+}
+// abs(z) > 0 as hypot decides it (driver.f90:209): an infinite component, or no NaN and a nonzero component (hypot of
+// finite arguments is at least the larger modulus: it never rounds a nonzero value to zero)
+UCF_DEV bool c_abs_positive(cplx z)
+{
+    const bool inf = d_isinf(z.re) || d_isinf(z.im);
+    const bool nan = d_isnan(z.re) || d_isnan(z.im);
+    return inf || (!nan && (z.re != 0.0 || z.im != 0.0));
 }
 
 // ---------------------------------------------------------------- real helpers
