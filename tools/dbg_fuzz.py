@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""replay flagged fuzz sets (gpurun_out/fuzz_flagged.json): sample-level errors of both flavours against binary128 along
-the abscissa range of the worst point.  usage: tools/dbg_fuzz.py seed set [seed set ...]"""
+"""replay flagged fuzz sets (tests/golden/fuzz_flagged_r02.json, or the fuzz_hunt.py result named by UCF_FUZZ_JSON):
+sample-level errors of both flavours against binary128 along the abscissa range of the worst point.
+usage: tools/dbg_fuzz.py seed set [seed set ...]"""
 import json, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,7 +11,7 @@ from unconfined_amd import engine
 from unconfined_amd.abi import params_from_deck
 import oracle_lib
 O, Oq = oracle_lib.Oracle(), oracle_lib.Oracle(quad=True)
-d = json.load(open(os.path.join(ROOT, "tests", "golden", "fuzz_flagged_r02.json")))
+d = json.load(open(os.environ.get("UCF_FUZZ_JSON", os.path.join(ROOT, "tests", "golden", "fuzz_flagged_r02.json"))))
 want = [(int(sys.argv[i]), int(sys.argv[i + 1])) for i in range(1, len(sys.argv) - 1, 2)]
 for r in d["flagged"]:
     if (r["seed"], r["set"]) not in want:
