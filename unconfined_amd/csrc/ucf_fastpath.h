@@ -23,6 +23,8 @@ struct fprim {
     double ch, sh, ei, sn, cs;    // cosh(x), sinh(x), exp(-|x|), sin(y), cos(y)
 };
 
+// POS: the caller knows x >= 0 (Re eta > 0 times a non-negative factor): no sign to put back on sinh
+template <bool POS = false>
 UCF_DEV fprim prim(double x, double y, const sc_ctx& sc)
 {
     const int salt = sc.salt;
@@ -44,7 +46,7 @@ UCF_DEV fprim prim(double x, double y, const sc_ctx& sc)
     } else {
         s = 0.5 * (e - ei);
     }
-    f.sh = copysign(s, x);
+    f.sh = POS ? s : copysign(s, x);
     sincos_tab_(y, sc, &f.sn, &f.cs);     // |y| < 1e6: fast_eta() vouches for it
     return f;
 }
@@ -189,20 +191,21 @@ UCF_DEV void fast_common_terms(const ucf_dev_params& P, const lane_consts& L, do
     S.have_p1 = (need_p1 && !z2) ? 1 : 0;      // kept only where fast_hantush_z derives the primitive of eta (1 - zD) from it
     fprim p1;
     if (need_p1) {
-        p1 = prim(S.eta.re, S.eta.im, S.sc);
+        p1 = prim<true>(S.eta.re, S.eta.im, S.sc);
         if (!z2) S.p1 = p1;
         S.che = pcosh(p1);
         S.she = psinh(p1);
-        S.ex1 = pexpneg(p1);
+        if (need_lay1) S.ex1 = pexpneg(p1);                    // (its only use: g3, below)
+        else S.ex1 = cmake(0.0, 0.0);
     } else {
         S.che = S.she = S.ex1 = cmake(0.0, 0.0);     // (read by lanes that do not use them: must be benign numbers)
     }
     if (hantush) {
         fprim pd;
-        if (!z1) { pd = prim(S.eta.re * P.dD, S.eta.im * P.dD, S.sc); S.ff1 = psinh(pd); }           // :176
+        if (!z1) { pd = prim<true>(S.eta.re * P.dD, S.eta.im * P.dD, S.sc); S.ff1 = psinh(pd); }           // :176
         else S.ff1 = cmake(0.0, 0.0);
         fprim pl;
-        if (!z2) { pl = prim(S.eta.re * P.lD1, S.eta.im * P.lD1, S.sc); S.ff2 = psinh(pl); }         // :177
+        if (!z2) { pl = prim<true>(S.eta.re * P.lD1, S.eta.im * P.lD1, S.sc); S.ff2 = psinh(pl); }         // :177
         else S.ff2 = cmake(0.0, 0.0);
         if (!(z1 && z2) || need_lay1) S.inv_she = cinv_auto(S.she);
         if (need_lay1) {                                                                        // :183-184
@@ -306,7 +309,7 @@ UCF_DEV cplx fast_hantush_z(const ucf_dev_params& P, const fast_common& S, doubl
     const bool need_chz = (lay == 1) || !z1 || (FAMILY == 2 && S.any_small) || FAMILY == 4;
     cplx chz = cmake(1.0, 0.0);
     fprim pz;
-    if (need_chz) { pz = prim(S.eta.re * zD, S.eta.im * zD, S.sc); chz = pcosh(pz); }
+    if (need_chz) { pz = prim<true>(S.eta.re * zD, S.eta.im * zD, S.sc); chz = pcosh(pz); }      // (0 <= zD <= 1 on this path)
     *chz_out = chz;
     cplx udp;
     if (lay == 1) {
