@@ -652,3 +652,36 @@ def test_random_parameter_sets_fast_vs_faithful():
 def test_smoke_entry():
     import __graft_entry__ as g
     g.smoke()
+
+
+def test_analytic_identities(engine):
+    """known answers of the reference's own formulation, at points where the inversion resolves them:
+    (1) model 0 is the Theis solution: h = E1(rD^2 / 4 tD) (dimensionless head, 4 pi T s / Q convention of the reference), to 1e-3;
+    (2) Hantush (model 1) with a fully penetrating well (d = 0, l = b) is Theis at every depth;
+    (3) model 4 (Malama, fully penetrating by construction) is model 5 with d = 0, l = b."""
+    from scipy.special import exp1
+    from unconfined_amd.abi import params_from_deck
+    dk, ts, P0 = load_deck("c1_theis")
+    tD = np.array([0.5, 2.0, 10.0, 50.0, 300.0]); rD = np.array([0.5, 1.0, 2.0, 1.0, 3.0])
+    for mode in MODES:
+        pl = engine.Plan(P0, mode=mode)
+        zD = np.array([0.5]); zl = pl.zlay(zD)
+        h0, _ = pl.drawdown(tD, rD, pl.split_vector(tD), zD, zl)
+        want = exp1(rD * rD / (4.0 * tD))
+        ratio = h0[:, 0] / want
+        # (to the accuracy of the reference's own scheme -- ten J0 intervals accelerated by Wynn-epsilon: ~1e-3, SURVEY.md 8c)
+        assert np.abs(ratio - 1.0).max() < 1e-3, (mode, ratio)
+        dh = load_deck("hantush_fullpen")[0]
+        dh = dh.replace(d=0.0, l=dh.b)
+        ph = engine.Plan(params_from_deck(dh), mode=mode)
+        pt = engine.Plan(params_from_deck(dh.replace(model=0)), mode=mode)
+        zz = np.array([0.1, 0.5, 0.9]); zlh = ph.zlay(zz)
+        hh, _ = ph.drawdown(tD, rD, ph.split_vector(tD), zz, zlh)
+        ht, _ = pt.drawdown(tD, rD, pt.split_vector(tD), zz, pt.zlay(zz))
+        assert rel_err(hh, ht, 1e-6).max() < 1e-9, (mode, float(rel_err(hh, ht, 1e-6).max()))
+        dm = load_deck("malama_fullpen")[0]
+        p4 = engine.Plan(params_from_deck(dm.replace(model=4)), mode=mode)
+        p5 = engine.Plan(params_from_deck(dm.replace(model=5, d=0.0, l=dm.b)), mode=mode)
+        h4, d4 = p4.drawdown(tD, rD, p4.split_vector(tD), zz, p4.zlay(zz))
+        h5, d5 = p5.drawdown(tD, rD, p5.split_vector(tD), zz, p5.zlay(zz))
+        assert rel_err(h4, h5, 1e-6).max() < 1e-9 and rel_err(d4, d5, 1e-6).max() < 1e-7, (mode, float(rel_err(h4, h5, 1e-6).max()))
