@@ -128,7 +128,6 @@ UCF_DEV lane_consts make_lane_consts(const ucf_dev_params& P, cplx p, cplx lt)
 struct fast_common {
     sc_ctx sc;           // sin/cos table in LDS + constants (sincos_tab_), set once per kernel; sc.salt = the loop counter
     cplx th, eta, ff1, ff2, inv_she, she, che, top, g3, inv_den, ex1;   // ex1 = exp(-eta)
-    cplx q, den;         // p + a^2; closure denominator (kept when inv_den = 1 / (q den), see fast_common_terms)
     fprim p1;            // primitive of eta itself (valid when have_p1)
     int have_p1;         // (wave-uniform flags are ints: a uniform bool that crosses a join is rebuilt through VALU selects)
     cplx fd_s1;          // FD: sigma(1)
@@ -155,7 +154,6 @@ UCF_DEV bool fast_eta(const ucf_dev_params& P, const lane_consts& L, double a, f
 {
     const double a2 = a * a;
     const cplx q = caddr(L.p, a2);
-    S.q = q;
     {
         const double r = fast_rcp(q.re * q.re + q.im * q.im);
         S.th = cmake(q.re * r, -(q.im * r));                      // HALF of theis = 2/q (:122-131): see fast_scale()
@@ -216,8 +214,7 @@ UCF_DEV void fast_common_terms(const ucf_dev_params& P, const lane_consts& L, do
         }
         if (FAMILY != 1) {
             // water-table value: hantush at zD = 1 (layer 3): g1 - g2                          (:81,162-170,196)
-            const bool top_th = (FAMILY != 2);                   // the water-table family keeps 1/q out of top (fast_sample_z)
-            S.top = S.top3 = top_th ? S.th : cmake(1.0, 0.0);
+            S.top = S.top3 = S.th;
             if (!(z1 && z2)) {
                 if (need_lay12) {
                     cplx g1;
@@ -226,7 +223,7 @@ UCF_DEV void fast_common_terms(const ucf_dev_params& P, const lane_consts& L, do
                     else if (P.share_g1top == 2) g1 = csub(pcosh(pd), cmul(rscale(P.g1_delta, S.eta), S.ff1));
                     else { const double c = P.dD1 - 1.0; g1 = pcosh(prim(S.eta.re * c, S.eta.im * c, S.sc)); }
                     const cplx udp = csub(g1, cmul(cadd(cmul(S.ff1, S.che), S.ff2), S.inv_she));
-                    S.top = top_th ? cmul(udp, S.th) : udp;                                     // :200 (x fast_scale)
+                    S.top = cmul(udp, S.th);                                                    // :200 (x fast_scale)
                 }
                 if (need_lay3) {
                     // For a depth above the screen top the rounding noise of that form matters (two terms of size
@@ -244,28 +241,23 @@ UCF_DEV void fast_common_terms(const ucf_dev_params& P, const lane_consts& L, do
                         else sd1 = psinh(prim(x1, S.eta.im * P.dD1, S.sc));
                     }
                     const cplx udp = cmul(z2 ? sd1 : csub(sd1, S.ff2), S.inv_she);
-                    S.top3 = top_th ? cmul(udp, S.th) : udp;
+                    S.top3 = cmul(udp, S.th);
                 }
             }
         }
     } else {
-        S.top = S.top3 = cmake(1.0, 0.0);                                                       // :78-79 (model 4: FAMILY 2)
+        S.top = S.top3 = S.th;                                                                  // :78-79
     }
     if (FAMILY == 2) {
         const cplx xi = cmul(S.eta, L.xifac);                                                   // :70-75
-        cplx den;
         if (P.beta != 0.0) {
             const cplx one_bex = radd(1.0, cmul(rscale(P.beta, S.eta), xi));
-            if (S.small_eta) den = cadd(cmul(one_bex, S.che), cmul(xi, S.she));                 // :86-87
-            else den = cadd(one_bex, xi);                                                       // :90-91
+            if (S.small_eta) S.inv_den = cinv_auto(cadd(cmul(one_bex, S.che), cmul(xi, S.she)));  // :86-87
+            else S.inv_den = cinv_auto(cadd(one_bex, xi));                                        // :90-91
         } else {                                                 // beta = 0 (wave-uniform): no product with (1, 0)
-            if (S.small_eta) den = cadd(S.che, cmul(xi, S.she));
-            else den = radd(1.0, xi);
+            if (S.small_eta) S.inv_den = cinv_auto(cadd(S.che, cmul(xi, S.she)));
+            else S.inv_den = cinv_auto(radd(1.0, xi));
         }
-        // the sample is (1/q) (udp - T f_z / den) = (udp den - T f_z) / (q den): ONE reciprocal instead of two, and 1/q is
-        // never formed (fast_sample_z)
-        S.den = den;
-        S.inv_den = cinv_auto(cmul(S.q, den));
     }
     if (FAMILY == 4) {
         // Mishra/Neuman finite-difference vadose zone (:444-544): sigma(1) of the tridiagonal system by
@@ -307,8 +299,7 @@ UCF_DEV bool fast_prepare(const ucf_dev_params& P, const lane_consts& L, double 
     return true;
 }
 
-// Hantush factor at depth zD (:133-202) WITHOUT its theis factor 1/q (the callers apply it: the water-table family folds
-// it into the one reciprocal of its closure); chz = cosh(eta*zD) is returned for the closure
+// Hantush factor at depth zD (:133-202); chz = cosh(eta*zD) is returned for the closure
 template <int FAMILY, bool FOLD = false, bool LAY3 = true>
 UCF_DEV cplx fast_hantush_z(const ucf_dev_params& P, const fast_common& S, double zD, int lay_in, cplx* chz_out,
                             cplx* exz_out)
@@ -340,7 +331,7 @@ UCF_DEV cplx fast_hantush_z(const ucf_dev_params& P, const fast_common& S, doubl
         cplx f2c = cmake(0.0, 0.0);
         if (!z2) f2c = cmul(S.ff2, pcosh(p1z));                  // sinh(eta lD1) cosh(eta (1 - zD))
         if (lay == 2 || !LAY3) {
-            if (z1 && z2) return cmake(1.0, 0.0);                                               // g2 = 0: udp = 1
+            if (z1 && z2) return S.th;                                                          // g2 = 0: udp = 1
             cplx num = f2c;
             if (!z1) num = cadd(cmul(S.ff1, chz), f2c);
             g2 = cmul(num, S.inv_she);                                                          // :179-180
@@ -358,7 +349,7 @@ UCF_DEV cplx fast_hantush_z(const ucf_dev_params& P, const fast_common& S, doubl
             udp = cmul(num, S.inv_she);
         }
     }
-    return udp;                                                                                 // (:200: x theis x fast_scale)
+    return cmul(udp, S.th);                                                                     // :200 (x fast_scale)
 }
 
 template <int FAMILY, bool FOLD = false, bool LAY3 = true>
@@ -367,26 +358,24 @@ UCF_DEV cplx fast_sample_z(const ucf_dev_params& P, const fast_common& S, int iz
     const double zD = P.zD[iz];
     const int lay = P.zLay[iz];
     cplx chz, exz = cmake(0.0, 0.0);
-    if (FAMILY == 1) return cmul(fast_hantush_z<1, FOLD, LAY3>(P, S, zD, lay, &chz, &exz), S.th);
+    if (FAMILY == 1) return fast_hantush_z<1, FOLD, LAY3>(P, S, zD, lay, &chz, &exz);
     if (FAMILY == 4) {
-        const cplx sH = cmul(fast_hantush_z<4, FOLD, LAY3>(P, S, zD, lay, &chz, &exz), S.th);
+        const cplx sH = fast_hantush_z<4, FOLD, LAY3>(P, S, zD, lay, &chz, &exz);
         if (!FOLD && LAY3 && lay == 3) return S.fd_use3 ? cadd(sH, cmul(S.fd_s13, chz)) : sH;
         return S.fd_use ? cadd(sH, cmul(S.fd_s1, chz)) : sH;                                    // :522-525
     }
-    // water-table family: sample = (1/q) (udp - T f_z / den) = (udp den - T f_z) / (q den), T = S.top (no theis factor in it,
-    // fast_common_terms), f_z = cosh(eta zD) or exp(eta (zD - 1)) (:85-91), S.inv_den = 1 / (q den)
-    cplx udp = cmake(1.0, 0.0);
+    cplx u;
     if (P.model == 4) {
+        u = S.th;
         if (S.any_small) chz = pcosh(prim(S.eta.re * zD, S.eta.im * zD, S.sc));
         if (S.any_large) { const double c = 1.0 - zD; exz = expneg_direct(S.eta.re * c, S.eta.im * c, S.sc); }
     } else {
-        udp = fast_hantush_z<2, FOLD, LAY3>(P, S, zD, lay, &chz, &exz);
+        u = fast_hantush_z<2, FOLD, LAY3>(P, S, zD, lay, &chz, &exz);
         if (S.any_large && lay == 1) { const double c = 1.0 - zD; exz = expneg_direct(S.eta.re * c, S.eta.im * c, S.sc); }
     }
-    const cplx fz = S.small_eta ? chz : exz;
-    if (FOLD || P.model == 4) return cmul(csub(S.den, fz), S.inv_den);          // udp = T = 1
-    const cplx top = (LAY3 && lay == 3) ? S.top3 : S.top;
-    return cmul(csub(cmul(udp, S.den), cmul(top, fz)), S.inv_den);
+    const cplx top = (!FOLD && LAY3 && P.model != 4 && lay == 3) ? S.top3 : S.top;
+    if (S.small_eta) return csub(u, cmul(cmul(top, chz), S.inv_den));                           // :85-87
+    return csub(u, cmul(cmul(top, exz), S.inv_den));                                            // :89-91
 }
 
 }  // namespace UCF_NS
