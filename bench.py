@@ -279,7 +279,38 @@ def worker(args):
     d_rD_fixed = torch.from_numpy(np.ascontiguousarray(rD_fixed)).to(dev)
     d_full = torch.zeros(2, prow * row, dtype=torch.float64, device=dev)      # [h; dh] x [prow][nr][nz]
 
+    # the gather of the strong-scaling step belongs to the product: ucf_drawdown_grid_allgather issues the rank's rows and the
+    # two in-place ncclAllGather calls on the same stream, over a communicator the library made itself (rank 0 draws the
+    # id, torch.distributed only carries its 128 bytes to the other ranks).  UCF_BENCH_GATHER=torch: the all-gather of
+    # torch.distributed instead (same layout; also what happens, loudly, if the library's communicator cannot be made)
+    lib_comm = None
+    gather_via = "none"
+    if world > 1:
+        gather_via = "torch.distributed all_gather_into_tensor" + ("" if backend == "nccl" else " (host-staged, rehearsal)")
+        if backend == "nccl" and os.environ.get("UCF_BENCH_GATHER", "ucf") != "torch":
+            try:
+                idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+                if rank == 0:
+                    idt.copy_(torch.frombuffer(bytearray(engine.comm_unique_id()), dtype=torch.uint8))
+                dist.broadcast(idt, 0)
+                torch.cuda.synchronize()
+                lib_comm = engine.comm_create(bytes(idt.cpu().numpy().tobytes()), world, rank)
+                gather_via = "ucf_drawdown_grid_allgather (in-place ncclAllGather on the launch stream, communicator from ucf_comm_create)"
+            except Exception as exc:
+                print(f"[bench] rank {rank}: the library's RCCL communicator is unavailable ({exc}); gathering with torch.distributed", file=sys.stderr)
+                lib_comm = None
+            ok_all = torch.tensor([1 if lib_comm else 0], device=dev)
+            dist.all_reduce(ok_all, op=dist.ReduceOp.MIN)          # all ranks or none
+            if int(ok_all.item()) == 0 and lib_comm:
+                engine.comm_destroy(lib_comm)
+                lib_comm = None
+                gather_via = "torch.distributed all_gather_into_tensor (a rank could not make the library's communicator)"
+
     def step_strong(gather=True):
+        if lib_comm and gather:
+            plan.drawdown_grid_allgather(lib_comm, rank, world, nt, d_tD.data_ptr(), d_sv.data_ptr(), nr, d_rD_fixed.data_ptr(), zD, zl,
+                                         d_full[0].data_ptr(), d_full[1].data_ptr(), stream=stream.cuda_stream)
+            return
         plan.drawdown_grid_shard_device(rank, world, nt, d_tD.data_ptr(), d_sv.data_ptr(), nr, d_rD_fixed.data_ptr(), zD, zl,
                                         d_full[0].data_ptr(), d_full[1].data_ptr(), stream=stream.cuda_stream)
         if world > 1 and gather:
@@ -389,6 +420,9 @@ def worker(args):
             other = {"scaling": "strong", "value": nt * nr * args.steps / e2, "ms_per_step": e2 / args.steps * 1e3,
                      "points_per_step": nt * nr}
 
+    if lib_comm:
+        torch.cuda.synchronize()
+        engine.comm_destroy(lib_comm)
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -439,6 +473,7 @@ def worker(args):
                    "points_per_step": pts_main, "points_per_gpu": pts_launch, "mode": args.mode, "layout": args.layout,
                    "partition": ("contiguous blocks of time rows (ucf_shard_rows), in-place all-gather of h and dh" if args.scaling == "strong"
                                  else "one block of radii per rank, all-gather of [h; dh]") + f", one rank per GPU, backend {backend if world > 1 else 'none'}",
+                   "gather": gather_via if args.scaling == "strong" else ("torch.distributed all_gather_into_tensor" if world > 1 else "none"),
                    "launcher": "self (bench.py spawned its ranks)" if os.environ.get("UCF_BENCH_SELF_LAUNCHED") else ("torch.distributed.run" if world > 1 else "single process"),
                    "build_id": build_id, "results_finite_and_gather_consistent": ok},
         "roofline": {"bound": "fp64_valu", "achieved": drow.get("executed_TFLOPs"), "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s",

@@ -233,6 +233,22 @@ int ucf_drawdown_grid_shard_device(ucf_plan* plan, int rank, int world, int nt, 
                                    int nr, const double* d_rD, int nz, const double* zD, const int* zLay,
                                    double* d_h, double* d_dh, ucf_stats* d_stats, void* stream);
 
+/* The same with the gather inside the library: the rank's rows, then one in-place ncclAllGather per array on `stream`
+ * (sendbuff = recvbuff + rank * B*nr*nz) over the RCCL communicator `comm` (an ncclComm_t passed as void*: the host's
+ * own, or one made by ucf_comm_create).  Asynchronous; d_h, d_dh must hold world*B rows.  RCCL is bound when the first
+ * of these entries is called (dlopen: libucf.so itself links no collective library); UCF_ERR_UNSUPPORTED without it.
+ * This is the "final RCCL gather over xGMI" of the sweep: the reference writes ONE file from one address space
+ * (driver.f90:245-273), every rank ends up holding that whole result. */
+int ucf_drawdown_grid_allgather(ucf_plan* plan, int rank, int world, int nt, const double* d_tD, const int* d_sv,
+                                int nr, const double* d_rD, int nz, const double* zD, const int* zLay,
+                                double* d_h, double* d_dh, ucf_stats* d_stats, void* comm, void* stream);
+/* A communicator of the library's own for hosts that have none: rank 0 draws the 128-byte id (ncclGetUniqueId) and hands
+ * it to the other ranks by whatever the host has (a file, MPI, torch.distributed ...); every rank then calls
+ * ucf_comm_create with the HIP device it computes on current (ncclCommInitRank). */
+int ucf_comm_unique_id(unsigned char* id128);
+int ucf_comm_create(const unsigned char* id128, int world, int rank, void** comm);
+int ucf_comm_destroy(void* comm);
+
 /* One process driving ngpu devices (the Fortran host): plans[g] was created with device g current (ucf_plan_create
  * binds a plan to the current HIP device) from the same parameters.  Host arrays in and out like ucf_drawdown_grid;
  * shard g runs on plans[g]'s device on a stream of its own, all devices at once, and the gather is each device's
@@ -280,6 +296,31 @@ int ucf_wynn_epsilon(int n, int nterms, const double* series_re_im /*[n][nterms]
 /* extraptozero, integration.f90:192-237 */
 int ucf_extraptozero(int n, int R, const double* x /*[R]*/, const double* y_re_im /*[n][R]*/,
                      double* out_re_im);
+
+/* The intermediate stages (driver.f90:129-216) of the PRODUCTION launch sequence: the call runs exactly what
+ * ucf_drawdown_grid (grid != 0: nt times x nr radii) or ucf_drawdown_batch on a list already ordered by radius (grid == 0:
+ * nt = nr = number of points, rD per point) would run for these sizes -- the same lane layout, kernel instantiations and
+ * launch bounds -- and then reads back what those kernels left in the plan's workspace:
+ *   state [npts][2M+1][(R+1+nacc)*nz] complex: per Laplace sample the level sums [R][nz] of the tanh-sinh part (WITHOUT the
+ *         factor arg/2 of driver.f90:135,154, which the finishing kernel applies), the area of the interval in progress
+ *         [nz], the finished J0-interval areas [nacc][nz] (driver.f90:201-203); zeros where the launch sequence keeps no
+ *         state (info[1] = 0: the monolithic kernel);
+ *   ndone [npts][2M+1]: abscissae the fast evaluators integrated (< nabs: the item was finished by the reference-order
+ *         evaluator, whose accumulators never leave the kernel: its state entries are what the hand-over was);
+ *   totlap [npts][nz][2M+1] complex: finint + infint (driver.f90:216);   h, dh [npts][nz].
+ * info[0..3] = lane layout used (0 sample, 1 time, 3 point), slots per sample, 2M+1, npts.  Needs nz <= the depths of
+ * one launch and sizes that make one launch sequence (UCF_ERR_UNSUPPORTED otherwise). */
+int ucf_debug_stages(ucf_plan* plan, int grid, int nt, const double* tD, const int* sv, int nr, const double* rD,
+                     int nz, const double* zD, const int* zLay, double* state, int* ndone, double* totlap,
+                     double* h, double* dh, int* info);
+/* wynn_epsilon as the finishing kernel runs it -- both epsilon columns in registers, at most 12 terms -- in flavour
+ * `mode` (0 faithful, 1 fast); same conventions as ucf_wynn_epsilon */
+int ucf_debug_wynn(int mode, int n, int nterms, const double* series_re_im, double* acc_re_im, int* status);
+/* deHoog_invlap as every grid call and long point list runs it (the tiled kernel: cooperative quotient-difference rhombus,
+ * continued fraction per lane): n transforms fp[n][2M+1] at times t[n], T = 2 t (driver.f90:106); h[n] = f(t),
+ * dh[n] = t * (inverse of p F(p)) (driver.f90:219-230) */
+int ucf_debug_dehoog_tiles(int mode, int n, int M, double alpha, double tol, const double* t, const double* fp_re_im,
+                           double* h, double* dh);
 
 /* K0(z), K1(z), Re z >= 0: cbesk(z, fnu=0, kode=1, n=2), cbessel.f90:877 -> cbknu :5036 (model 2);
  * k_re_im[n][2][2] = (K0, K1), ierr[n] as cbesk's IERR */

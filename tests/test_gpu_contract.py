@@ -372,3 +372,108 @@ def test_far_field_points_keep_their_accuracy(engine, oracle, oracle_quad):
         ht, _ = oracle_quad.batch(P, tD[sl], rD[sl], sv[sl], zD, zl)
         e_fast, e_ref = np.abs(h[0] - ht[0]) / np.abs(ht[0]), np.abs(ho[0] - ht[0]) / np.abs(ht[0])
         assert (e_fast <= 20.0 * np.maximum(e_ref, 1e-12)).all(), (seed, e_fast.tolist(), e_ref.tolist())
+
+
+@pytest.mark.parametrize("mode", ["fast", "faithful"])
+def test_host_grid_entry_reuses_its_workspace(engine, mode):
+    """the host grid entry (ucf_drawdown_grid = ucf_drawdown_grid_multi with one plan: Python Plan.drawdown_grid, the CLI,
+    the Fortran host) runs on a stream that the PLAN owns, so its workspace is found again by every later call: twenty
+    calls on one plan allocate what the first one allocated, ucf_plan_update (which waits for every stream a workspace is
+    keyed by) works afterwards, and the results stay what a fresh plan computes"""
+    from unconfined_amd.abi import params_from_deck
+    dk, ts, P = load_deck("neuman74_partpen")
+    plan = engine.Plan(P, mode=mode)
+    zD = np.array([0.3, 0.91]); zl = plan.zlay(zD)
+    tD, sv, rD = _grid_inputs(plan, 130, 7)
+    ref = plan.drawdown_grid(tD, sv, rD, zD, zl)
+    n0 = plan.alloc_count()
+    assert n0 > 0
+    for _ in range(20):
+        h, dh = plan.drawdown_grid(tD, sv, rD, zD, zl)
+        assert np.array_equal(h, ref[0], equal_nan=True) and np.array_equal(dh, ref[1], equal_nan=True)
+    assert plan.alloc_count() == n0, (n0, plan.alloc_count())
+    # smaller calls and the multi-plan form with this plan reuse the same workspace too
+    plan.drawdown_grid(tD[:64], sv[:64], rD[:3], zD, zl)
+    engine.drawdown_grid_multi([plan], tD, sv, rD, zD, zl)
+    assert plan.alloc_count() == n0
+    # new parameters for the same plan: every stream in the plan's workspace list is alive
+    Pn = params_from_deck(dk.replace(Kr=dk.Kr * 1.7, kappa=dk.kappa * 0.6, Sy=dk.Sy * 0.9))
+    plan.update(Pn)
+    fresh = engine.Plan(Pn, mode=mode)
+    tD2 = tD * (plan.derived.Tc / fresh.derived.Tc)          # (same numbers: Tc is the fresh plan's own)
+    a = plan.drawdown_grid(tD2, plan.split_vector(tD2), rD, zD, plan.zlay(zD))
+    b = fresh.drawdown_grid(tD2, fresh.split_vector(tD2), rD, zD, fresh.zlay(zD))
+    assert np.array_equal(a[0], b[0], equal_nan=True) and np.array_equal(a[1], b[1], equal_nan=True)
+    assert plan.alloc_count() == n0
+
+
+def test_allgather_entry_over_the_librarys_own_communicator(engine):
+    """ucf_drawdown_grid_allgather: the rank's rows and the in-place ncclAllGather of h and dh, issued by the library on
+    the caller's stream over a communicator from ucf_comm_create.  One GPU here, so the communicator has one rank (RCCL
+    refuses two ranks on one device): the entry point, the run-time binding of RCCL, the communicator life cycle and the
+    in-place form of the collective run for real; the rows equal the grid entry's bit for bit"""
+    import torch
+    from unconfined_amd import sharding
+    dk, ts, P = load_deck("c2_neuman74_fullpen")
+    plan = engine.Plan(P, mode="fast")
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    zD = np.array([0.91]); zl = plan.zlay(zD)
+    nt, nr = 200, 5
+    tD, sv, rD = _grid_inputs(plan, nt, nr)
+    ref = plan.drawdown_grid(tD, sv, rD, zD, zl)
+    uid = engine.comm_unique_id()
+    assert len(uid) == 128
+    comm = engine.comm_create(uid, 1, 0)
+    assert comm
+    try:
+        d_t = torch.tensor(tD, device=dev); d_s = torch.tensor(sv, dtype=torch.int32, device=dev); d_r = torch.tensor(rD, device=dev)
+        full = torch.full((2, sharding.padded_rows(nt, 1) * nr), -7.0, dtype=torch.float64, device=dev)
+        s = torch.cuda.Stream(device=dev)
+        s.wait_stream(torch.cuda.current_stream())
+        for _ in range(2):
+            plan.drawdown_grid_allgather(comm, 0, 1, nt, d_t.data_ptr(), d_s.data_ptr(), nr, d_r.data_ptr(), zD, zl, full[0].data_ptr(),
+                                         full[1].data_ptr(), stream=s.cuda_stream)
+        s.synchronize()
+        got = full.cpu().numpy().reshape(2, nt, nr, 1)
+        assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+    finally:
+        engine.comm_destroy(comm)
+    from unconfined_amd.lib import UcfError
+    with pytest.raises(UcfError):
+        plan.drawdown_grid_allgather(0, 0, 1, nt, 1, 1, nr, 1, zD, zl, 1, 1)        # no communicator
+
+
+_GROUPS_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+from golden_util import load_deck
+from unconfined_amd import engine
+from unconfined_amd.abi import params_from_deck
+dk, ts, P = load_deck("neuman74_partpen")
+plans = [engine.Plan(params_from_deck(dk.replace(Kr=dk.Kr * (0.6 + 0.07 * i), kappa=dk.kappa * (0.5 + 0.1 * i))), mode="fast") for i in range(11)]
+rng = np.random.default_rng(3)
+t = 10.0 ** rng.uniform(-1, 4, 90); r = rng.choice([30.0, 85.1, 400.0], 90); z = np.array([145.7, 60.0])
+hm, dhm = engine.drawdown_multi(plans, t, r, z)
+np.savez(sys.argv[2], h=hm, dh=dhm)
+"""
+
+
+def test_parameter_batch_in_groups_equals_one_group(tmp_path):
+    """ucf_drawdown_multi with its plans on several devices runs one launch sequence per device and merges by plan index.
+    One GPU here: UCF_MULTI_GROUPS cuts the one device's plans into 2 / 3 groups (own host threads, own launch
+    sequences) -- the results must be those of the single group, bit for bit"""
+    import os, subprocess, sys
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for tag, env in (("one", {}), ("two", {"UCF_MULTI_GROUPS": "2"}), ("three", {"UCF_MULTI_GROUPS": "3"})):
+        out = str(tmp_path / f"{tag}.npz")
+        e = dict(os.environ); e.update(env)
+        subprocess.run([sys.executable, "-c", _GROUPS_SCRIPT, root, out], check=True, env=e, timeout=600)
+        res[tag] = np.load(out)
+    assert np.isfinite(res["one"]["h"]).all()
+    for tag in ("two", "three"):
+        assert np.array_equal(res[tag]["h"], res["one"]["h"]) and np.array_equal(res[tag]["dh"], res["one"]["dh"]), tag

@@ -1031,6 +1031,9 @@ __global__ void __launch_bounds__(256)
 abscissa_kernel(const ucf_dev_params P, int nrows, int per_point, int nsv, int svmin,
                 const double* __restrict__ rDv, const int* __restrict__ svv, double2* __restrict__ tab)
 {
+    // P.tab_premul (fast flavour): the Gauss-Lobatto entries carry their quadrature weight, a J0(a rD) w_m, so that the
+    // abscissa loop accumulates a sample with one FMA per component (the faithful flavour keeps the reference's
+    // ((a J0 f) lapTime) w order and multiplies by w_m itself)
     const int nabs = P.N + P.nacc * P.ngl;
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (long long)nrows * nabs) return;
@@ -1039,7 +1042,7 @@ abscissa_kernel(const ucf_dev_params P, int nrows, int per_point, int nsv, int s
     int sv;
     if (per_point) { rD = rDv[row]; sv = svv[row]; }
     else { rD = rDv[row / nsv]; sv = svmin + row % nsv; }
-    double a;
+    double a, w = 1.0;
     if (n < P.N) {
         const double arg = P.j0z[sv - 1] / rD;                                                  // driver.f90:120
         a = (P.ts_x[n] * arg) / 2.0;                                                            // integration.f90:62
@@ -1049,8 +1052,10 @@ abscissa_kernel(const ucf_dev_params P, int nrows, int per_point, int nsv, int s
         const double hib = P.j0z[sv + jj] / rD;
         const double width = hib - lob;
         a = (width * P.gl_x[m] + (hib + lob)) / 2.0;                                            // :193
+        if (P.tab_premul) w = P.gl_w[m];
     }
-    tab[gid] = make_double2(a, a * j0(a * rD));
+    const double aj = a * j0(a * rD);
+    tab[gid] = make_double2(a, P.tab_premul ? aj * w : aj);
 }
 #endif
 
@@ -1203,6 +1208,7 @@ UCF_DEV void finish_item(const ucf_dev_params& P, lds_c* accTS, lds_c* scr, cons
         } else if (LAYOUT == 2) {
             if (W.live) totlap[((size_t)W.pidx * nz + z) * P.np + W.mlap] = make_double2(tl.re, tl.im);
         } else {
+            if (totlap && W.live) totlap[((size_t)pt * nz + z) * P.np + W.mlap] = make_double2(tl.re, tl.im);   // (ucf_debug_stages only)
             const double hval = dehoog_wave(tl, P.M, P.alpha, P.logtol, tD, tee, lane, st);      // :219-223
             const double dval = dehoog_wave(cmul(tl, p), P.M, P.alpha, P.logtol, tD, tee, lane, st) * tD;   // :225-230
             if (lane == 0) {
@@ -1302,7 +1308,7 @@ point_kernel(const ucf_dev_params P0, int npts, int per_point, int nr, int nsv, 
             } else {
                 const int g = n - N;
                 const int jj = g / ngl, m = g - jj * ngl;
-                cplx acc = cadd(lds_ld(accCur, z, lane), cscale(val, P.gl_w[m]));               // :201-202
+                cplx acc = cadd(lds_ld(accCur, z, lane), cscale(val, P0.tab_premul ? 1.0 : P.gl_w[m]));   // :201-202
                 if (m == ngl - 1) {
                     const double lob = P.j0z[sv + jj - 1] / rD;
                     const double hib = P.j0z[sv + jj] / rD;
@@ -1353,7 +1359,7 @@ point_kernel(const ucf_dev_params P0, int npts, int per_point, int nr, int nsv, 
 // fully penetrating; 5; else 4)
 // UCF_IWPB waves per workgroup: they share nothing but the sin/cos table of sincos_tab_ in LDS (4 KB, copied once from
 // the plan's tables; one barrier, before the work loop); every wave keeps walking its own work items.
-template <int FAMILY, int LAYOUT, int WAVES, bool MULTI, bool FOLD, bool LAY3>
+template <int FAMILY, int LAYOUT, int WAVES, bool MULTI, bool FOLD, bool LAY3, int NZC = 0>      // NZC = 1: one depth per launch, known at compile time
 __global__ void __launch_bounds__(UCF_WAVE * UCF_IWPB, WAVES)
 integrate_kernel(const ucf_dev_params P0, int npts, int per_point, int nr, int nsv, int svmin,
                  const double* __restrict__ tDv, const double* __restrict__ rDv, const int* __restrict__ svv,
@@ -1365,8 +1371,10 @@ integrate_kernel(const ucf_dev_params P0, int npts, int per_point, int nr, int n
     const ucf_dev_params& P = P0;
     UCF_K1_ASSUME      // tools/: specialise a probe build to one plan shape to read its inner loop
 #endif
-    const int lane = threadIdx.x & (UCF_WAVE - 1), wv = threadIdx.x / UCF_WAVE;
-    const int nz = P0.nz, R = P0.R, nacc = P0.nacc, N = P0.N, ngl = P0.ngl;
+    // (the wave's index within the workgroup is wave-uniform, but only readfirstlane tells the compiler: without it the
+    //  work item, its abscissa row and the row's entries live in VGPRs and are fetched by vector loads)
+    const int lane = threadIdx.x & (UCF_WAVE - 1), wv = __builtin_amdgcn_readfirstlane(threadIdx.x / UCF_WAVE);
+    const int nz = NZC ? NZC : P0.nz, R = P0.R, nacc = P0.nacc, N = P0.N, ngl = P0.ngl;
     __builtin_assume(nz >= 1 && R >= 1 && nacc >= 1 && ngl >= 1);     // (the launcher's business: no loop guards in the kernel)
     const int nabs = N + nacc * ngl;
     // LDS: [256] sin/cos table | per wave: [R][nz] level sums, [nz] area of the J0 interval being integrated
@@ -1399,6 +1407,10 @@ integrate_kernel(const ucf_dev_params P0, int npts, int per_point, int nr, int n
         for (int s = 0; s < (R + 1) * nz; s++) lds_st(wlds, s, lane, cmake(0.0, 0.0));
         fast_common F;
         sc_ctx_init(F.sc, sct, UCF_KV(FAMILY, FOLD));
+        // the closure's unscaled reciprocal (fast_common_terms) wants |xi| = |eta| |xifac| far from overflow: an item with a
+        // lane beyond that goes to point_kernel whole
+        const bool lane_ok = FAMILY != 2 || (fabs(LC.xifac.re) + fabs(LC.xifac.im) < 1.0e90);
+        const int nlim = (__builtin_amdgcn_ballot_w64(!lane_ok) == 0) ? nabs : 0;
 
         // abscissae increase monotonically (tanh-sinh on [0,arg], then the J0 intervals), so does Re(eta):
         // the fast evaluation is valid for a leading run of abscissae; point_kernel finishes the rest.
@@ -1407,10 +1419,9 @@ integrate_kernel(const ucf_dev_params P0, int npts, int per_point, int nr, int n
         double2 aa = row[0];
         int m = 0, jj = 0;                        // Gauss-Lobatto node and J0 interval of abscissa n >= N
         cplx acc0 = cmake(0.0, 0.0);              // running area of the interval: a register when nz = 1,
-        for (; n < nabs; n++) {                   // else accCur[z] in LDS
+        for (; n < nlim; n++) {                   // else accCur[z] in LDS
             const double2 nxt = row[n + 1 < nabs ? n + 1 : n];
             const bool ts = n < N;
-            const double w = ts ? 0.0 : P.gl_w[m];
             F.sc.salt = n;
             if (__builtin_amdgcn_ballot_w64(!fast_eta<FAMILY>(P, LC, aa.x, F)) != 0) break;      // (every lane is live here)
             fast_common_terms<FAMILY, FOLD, LAY3>(P, LC, aa.x, need_lay1, F, need_lay3, need_lay12);
@@ -1419,8 +1430,10 @@ integrate_kernel(const ucf_dev_params P0, int npts, int per_point, int nr, int n
             if (tz > R - 1) tz = R - 1;
             for (int z = 0; z < nz; z++) {
                 // val = a*J0(a rD) * f(a,p,z) [* lapTime(p): at the end]                         (lhs.f90:118)
-                const cplx val = rscale(aa.y, fast_sample_z<FAMILY, FOLD, LAY3>(P, F, z));
+                // (Gauss-Lobatto part: aa.y carries the node's weight, abscissa_kernel)
+                const cplx fz = fast_sample_z<FAMILY, FOLD, LAY3>(P, F, z);
                 if (ts) {
+                    const cplx val = rscale(aa.y, fz);
                     // tanh-sinh on [0, arg]: abscissa n+1 belongs to level j when 2^(R-j) divides it  (driver.f90:129-157)
                     for (int sh = 0; sh <= tz; sh++) {
                         const int j = R - sh;
@@ -1429,9 +1442,10 @@ integrate_kernel(const ucf_dev_params P0, int npts, int per_point, int nr, int n
                         lds_st(accTS, slot, lane, cadd(lds_ld(accTS, slot, lane), rscale(wl, val)));
                     }
                 } else if (nz == 1) {
-                    acc0 = cadd(acc0, cscale(val, w));                                          // :201-202
+                    acc0 = cmake(__builtin_fma(fz.re, aa.y, acc0.re), __builtin_fma(fz.im, aa.y, acc0.im));       // :201-202
                 } else {
-                    lds_st(accCur, z, lane, cadd(lds_ld(accCur, z, lane), cscale(val, w)));
+                    const cplx a1 = lds_ld(accCur, z, lane);
+                    lds_st(accCur, z, lane, cmake(__builtin_fma(fz.re, aa.y, a1.re), __builtin_fma(fz.im, aa.y, a1.im)));
                 }
             }
             if (!ts && ++m == ngl) {
@@ -1519,7 +1533,7 @@ integrate_generic_kernel(const ucf_dev_params P, int npts, int per_point, int nr
                         }
                     }
                 } else {
-                    cplx acc = cadd(lds_ld(accCur, z, lane), cscale(val, P.gl_w[m]));           // :201-202
+                    cplx acc = cadd(lds_ld(accCur, z, lane), cscale(val, P.tab_premul ? 1.0 : P.gl_w[m]));   // :201-202
                     if (m == ngl - 1) {
                         const double lob = P.j0z[sv + jj - 1] / rD;
                         const double hib = P.j0z[sv + jj] / rD;
@@ -1738,7 +1752,8 @@ samples_kernel(const ucf_dev_params P, int n_a, const double* __restrict__ av, d
     }
     if (FAMILY == 1 || FAMILY == 2 || FAMILY == 4) {
         const lane_consts LC = make_lane_consts(P, p, lt);
-        fast = __all(fast_prepare<FAMILY>(P, LC, a, need_lay1, F));
+        const bool lane_ok = FAMILY != 2 || (fabs(LC.xifac.re) + fabs(LC.xifac.im) < 1.0e90);      // as integrate_kernel
+        fast = __all(lane_ok && fast_prepare<FAMILY>(P, LC, a, need_lay1, F));
     }
 #endif
     const cplx lane_aux = (FAMILY == 5) ? hstorage_A0(P, p) : cmake(0.0, 0.0);
@@ -1759,6 +1774,77 @@ samples_kernel(const ucf_dev_params P, int n_a, const double* __restrict__ av, d
         }
     }
 }
+
+// ucf_debug_stages: the state that the transform kernel of the PRODUCTION launch sequence left in the workspace, brought
+// from its work-item order (decode_item: the layout the launcher chose) into [point][Laplace index][slot]
+#if !UCF_FAST
+template <int LAYOUT>
+__global__ void __launch_bounds__(UCF_WAVE)
+debug_gather_kernel(const ucf_dev_params P, int nwork, int per_point, int nr, int nt, int ir0, const double2* __restrict__ state,
+                    const int* __restrict__ ndone, double2* __restrict__ out_state, int* __restrict__ out_ndone)
+{
+    const int lane = threadIdx.x;
+    const int slots = (int)state_slots(P);
+    for (int pt = blockIdx.x; pt < nwork; pt += gridDim.x) {
+        const work_item W = decode_item<LAYOUT>(P, pt, lane, per_point, nr, nt, ir0, nwork);
+        if (!W.live) continue;
+        const size_t q = (LAYOUT == 1) ? (size_t)W.it * nr + W.ir : (size_t)W.pidx;
+        for (int sl = 0; sl < slots; sl++)
+            out_state[(q * P.np + W.mlap) * slots + sl] = state[((size_t)pt * slots + sl) * UCF_WAVE + lane];
+        out_ndone[q * P.np + W.mlap] = ndone[pt];
+    }
+}
+int launch_debug_gather(const ucf_dev_params& dp, int layout, int nwork, int per_point, int nr, int nt, int ir0, const double* d_state,
+                        const int* d_ndone, double* d_out_state, int* d_out_ndone, void* stream)
+{
+    const dim3 grid((unsigned)(nwork < 65536 ? nwork : 65536)), block(UCF_WAVE);
+    hipStream_t s = (hipStream_t)stream;
+    if (layout == 0) hipLaunchKernelGGL(debug_gather_kernel<0>, grid, block, 0, s, dp, nwork, per_point, nr, nt, ir0, (const double2*)d_state, d_ndone, (double2*)d_out_state, d_out_ndone);
+    else if (layout == 1) hipLaunchKernelGGL(debug_gather_kernel<1>, grid, block, 0, s, dp, nwork, per_point, nr, nt, ir0, (const double2*)d_state, d_ndone, (double2*)d_out_state, d_out_ndone);
+    else if (layout == 3) hipLaunchKernelGGL(debug_gather_kernel<3>, grid, block, 0, s, dp, nwork, per_point, nr, nt, ir0, (const double2*)d_state, d_ndone, (double2*)d_out_state, d_out_ndone);
+    else return UCF_ERR_UNSUPPORTED;
+    return hipGetLastError() == hipSuccess ? UCF_OK : UCF_ERR_HIP;
+}
+#endif
+
+#if UCF_TU_HAS(1)
+// ucf_debug_wynn: the register-resident epsilon table that finish_kernel runs (wynn_regs<UCF_WYNN_REGS>), lane = problem
+__global__ void __launch_bounds__(UCF_WAVE, 3)
+wynn_regs_kernel(int n, int nterms, const double* __restrict__ series, double* __restrict__ acc, int* __restrict__ status)
+{
+    const int i = blockIdx.x * UCF_WAVE + threadIdx.x;
+    const int ii = i < n ? i : n - 1;
+    cplx ser[UCF_WYNN_REGS];
+#pragma unroll
+    for (int k = 0; k < UCF_WYNN_REGS; k++) {
+        ser[k] = cmake(0.0, 0.0);
+        if (k < nterms) ser[k] = cmake(series[((size_t)ii * nterms + k) * 2], series[((size_t)ii * nterms + k) * 2 + 1]);
+    }
+    int stt = 0;
+    const cplx r = wynn_regs<UCF_WYNN_REGS>(ser, nterms, &stt);
+    if (i < n) {
+        acc[2 * i] = r.re;
+        acc[2 * i + 1] = r.im;
+        status[i] = stt;
+    }
+}
+int launch_wynn_regs(int n, int nterms, const double* d_series, double* d_acc, int* d_status, void* stream)
+{
+    if (nterms > UCF_WYNN_REGS) return UCF_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(wynn_regs_kernel, dim3((n + UCF_WAVE - 1) / UCF_WAVE), dim3(UCF_WAVE), 0, (hipStream_t)stream, n, nterms, d_series, d_acc, d_status);
+    return hipGetLastError() == hipSuccess ? UCF_OK : UCF_ERR_HIP;
+}
+// ucf_debug_dehoog_tiles: dehoog_tiles_kernel itself -- the kernel every grid and every long point list ends with -- on a
+// transform given as [m][n] (one radius, one depth, n times)
+int launch_dehoog_tiles_hook(const ucf_dev_params& dp, int n, const double* d_tD, const double* d_totlap, double* d_h, double* d_dh, void* stream)
+{
+    const long long ntl = (n + UCF_DH_TILE - 1) / UCF_DH_TILE;
+    const size_t dlds = 2 * (size_t)dp.np * (UCF_DH_TILE + 1) * sizeof(lds_c) + 2 * UCF_DH_TILE * sizeof(int);
+    hipLaunchKernelGGL(dehoog_tiles_kernel<1>, dim3((unsigned)ntl), dim3(UCF_WAVE), dlds, (hipStream_t)stream, dp, n, 1, 0, 1, d_tD,
+                       (const double2*)d_totlap, d_h, d_dh, (ucf_stats*)nullptr);
+    return hipGetLastError() == hipSuccess ? UCF_OK : UCF_ERR_HIP;
+}
+#endif
 
 #if !UCF_FAST
 __global__ void __launch_bounds__(UCF_WAVE)
@@ -1840,6 +1926,9 @@ extrap_kernel(int n, int R, const double* __restrict__ x, const double* __restri
 #endif
 
 // ------------------------------------------------------------------ launchers
+#ifdef UCF_PROBE      /* tools/probe_kernel.sh: one kernel instantiation on its own (seconds instead of minutes), no launchers */
+const void* ucf_probe_kernel_address = (const void*)&UCF_PROBE;
+#else
 static inline int family_of(const ucf_dev_params& dp)
 {
     switch (dp.model) {
@@ -1955,14 +2044,22 @@ static int launch_transform_(const ucf_dev_params& dp, int nwork, int per_point,
         const size_t wlds = (size_t)(dp.R + 1) * dp.nz * UCF_WAVE * sizeof(lds_c) + UCF_SC_ENTRIES * sizeof(lds_c) / UCF_IWPB;
         const size_t ilds = wlds * UCF_IWPB;
         const dim3 igrid((unsigned)((nwork + UCF_IWPB - 1) / UCF_IWPB)), iblock(UCF_WAVE * UCF_IWPB);
-#define UCF_LAUNCH_I3(F, W, FO, L3)                                                                            \
+#define UCF_LAUNCH_I4(F, W, FO, L3, NZC)                                                                       \
     do {                                                                                                       \
         if (ilds > 64 * 1024)                                                                                  \
-            (void)hipFuncSetAttribute((const void*)integrate_kernel<F, LAYOUT, W, MULTI, FO, L3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ilds); \
-        std::snprintf(kname, sizeof(kname), UCF_STR(UCF_NS) "::integrate_kernel<%d, %d, %d, %s, %s, %s>", F, LAYOUT, W, MULTI ? "true" : "false", FO ? "true" : "false", L3 ? "true" : "false"); \
+            (void)hipFuncSetAttribute((const void*)integrate_kernel<F, LAYOUT, W, MULTI, FO, L3, NZC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ilds); \
+        std::snprintf(kname, sizeof(kname), UCF_STR(UCF_NS) "::integrate_kernel<%d, %d, %d, %s, %s, %s, %d>", F, LAYOUT, W, MULTI ? "true" : "false", FO ? "true" : "false", L3 ? "true" : "false", NZC); \
         ucf_tm_mark(tm, kname, s);                                                                             \
-        hipLaunchKernelGGL((integrate_kernel<F, LAYOUT, W, MULTI, FO, L3>), igrid, iblock, ilds, s, dp, nwork, per_point, nr, nsv, svmin, \
+        hipLaunchKernelGGL((integrate_kernel<F, LAYOUT, W, MULTI, FO, L3, NZC>), igrid, iblock, ilds, s, dp, nwork, per_point, nr, nsv, svmin, \
                            d_tD, d_rD, d_sv, (const double2*)d_tab, nt, ir0, (double2*)d_state, d_ndone, d_todo, d_params, ppp, pbase); \
+    } while (0)
+#ifndef UCF_NZC
+#define UCF_NZC 0              /* 1: launches of one depth run the instantiation that knows nz = 1 at compile time */
+#endif
+#define UCF_LAUNCH_I3(F, W, FO, L3)                                                                            \
+    do {                                                                                                       \
+        if (UCF_NZC && dp.nz == 1) UCF_LAUNCH_I4(F, W, FO, L3, (UCF_NZC ? 1 : 0));                             \
+        else UCF_LAUNCH_I4(F, W, FO, L3, 0);                                                                   \
     } while (0)
         // a depth above the screen top anywhere in the call (in any plan of a parameter batch)?
         const bool lay3 = dp.any_lay3 != 0;
@@ -1997,6 +2094,7 @@ static int launch_transform_(const ucf_dev_params& dp, int nwork, int per_point,
 #undef UCF_LAUNCH_FOLD
 #undef UCF_LAUNCH_UNF
 #undef UCF_LAUNCH_I3
+#undef UCF_LAUNCH_I4
     }
 #endif
     if (kind == 2) {
@@ -2092,9 +2190,13 @@ static int launch_transform(const ucf_dev_params& dp, int nwork, int per_point, 
 {
 #if UCF_FAST
     if (d_params) {
-        if (LAYOUT == 1 || !per_point) return UCF_ERR_BAD_ARGUMENT;      // (layouts 0, 2, 3)
-        return launch_transform_<(LAYOUT == 1 ? 0 : LAYOUT), true>(dp, nwork, per_point, nr, nsv, svmin, d_tD, d_rD, d_sv, d_tab, d_h, d_dh, d_stats, nt,
-                                                                  ir0, nrc, d_totlap, d_glscr, d_state, d_ndone, stream, tm, d_params, ppp, pbase);
+        // parameter batches run in the per-point layouts 0, 2, 3 (the lane = time translation unit instantiates none of it)
+        if constexpr (LAYOUT == 1) return UCF_ERR_BAD_ARGUMENT;
+        else {
+            if (!per_point) return UCF_ERR_BAD_ARGUMENT;
+            return launch_transform_<LAYOUT, true>(dp, nwork, per_point, nr, nsv, svmin, d_tD, d_rD, d_sv, d_tab, d_h, d_dh, d_stats, nt,
+                                                   ir0, nrc, d_totlap, d_glscr, d_state, d_ndone, stream, tm, d_params, ppp, pbase);
+        }
     }
 #else
     if (d_params) return UCF_ERR_UNSUPPORTED;
@@ -2108,10 +2210,10 @@ static int launch_transform(const ucf_dev_params& dp, int nwork, int per_point, 
 int launch_points(const ucf_dev_params& dp, int npts, int per_point, int nr, int nsv, int svmin, const double* d_tD,
                   const double* d_rD, const int* d_sv, const double* d_tab, double* d_h, double* d_dh,
                   ucf_stats* d_stats, void* stream, double* d_glscr, double* d_state, int* d_ndone,
-                  const ucf_dev_params* d_params, int ppp, int pbase)
+                  const ucf_dev_params* d_params, int ppp, int pbase, double* d_dbg_totlap)
 {
     return launch_transform<0>(dp, npts, per_point, nr, nsv, svmin, d_tD, d_rD, d_sv, d_tab, d_h, d_dh, d_stats, 0, 0, 0,
-                               nullptr, d_glscr, d_state, d_ndone, stream, nullptr, d_params, ppp, pbase);
+                               d_dbg_totlap, d_glscr, d_state, d_ndone, stream, nullptr, d_params, ppp, pbase);
 }
 
 #endif
@@ -2243,5 +2345,6 @@ int launch_extrap(int n, int R, const double* d_x, const double* d_y, double* d_
     return hipGetLastError() == hipSuccess ? UCF_OK : UCF_ERR_HIP;
 }
 #endif
+#endif   // UCF_PROBE
 
 }  // namespace UCF_NS

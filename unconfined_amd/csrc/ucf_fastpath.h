@@ -29,11 +29,12 @@ UCF_DEV fprim prim(double x, double y, const sc_ctx& sc)
 {
     const int salt = sc.salt;
     fprim f;
-    const double ax = fabs(x);
+    const double ax = POS ? x : fabs(x);          // (POS: the absolute value would be two VALU instructions in front of the inline asm)
     const double e = exp_tab_(ax, sc);
     const double ei = fast_rcp(e);
     f.ei = ei;
-    f.ch = 0.5 * (e + ei);
+    const double he = 0.5 * e;
+    f.ch = __builtin_fma(0.5, ei, he);
     double s;
     if (ax < 0.35) {
         const double x2 = ax * ax;
@@ -44,7 +45,7 @@ UCF_DEV fprim prim(double x, double y, const sc_ctx& sc)
         pl = fmak(pl, x2, UCF_KHERE(1.0 / 6.0, salt));
         s = __builtin_fma(ax * x2, pl, ax);
     } else {
-        s = 0.5 * (e - ei);
+        s = __builtin_fma(-0.5, ei, he);
     }
     f.sh = POS ? s : copysign(s, x);
     sincos_tab_(y, sc, &f.sn, &f.cs);     // |y| < 1e6: fast_eta() vouches for it
@@ -79,6 +80,16 @@ UCF_DEV cplx expneg_direct(double x, double y, const sc_ctx& sc)
     return cmake(ei * cs, -(ei * sn));
 }
 
+// a b + c in four FMAs (one rounding less per component than product, then sum)
+UCF_DEV cplx cfma(cplx a, cplx b, cplx c)
+{
+    return cmake(__builtin_fma(a.re, b.re, __builtin_fma(-a.im, b.im, c.re)), __builtin_fma(a.re, b.im, __builtin_fma(a.im, b.re, c.im)));
+}
+// c - a b
+UCF_DEV cplx cfnma(cplx a, cplx b, cplx c)
+{
+    return cmake(__builtin_fma(-a.re, b.re, __builtin_fma(a.im, b.im, c.re)), __builtin_fma(-a.re, b.im, __builtin_fma(-a.im, b.re, c.im)));
+}
 // 1/z without scaling: |z| in [1e-150, 1e150]
 UCF_DEV cplx cinv_plain(cplx z)
 {
@@ -166,7 +177,7 @@ UCF_DEV bool fast_eta(const ucf_dev_params& P, const lane_consts& L, double a, f
         S.eta = cmake(r, qi * hr);
     }
     // (three compares and two scalar ANDs; the short-circuit form rebuilt the flag through a select)
-    return (bool)((int)(S.eta.re <= P.fast_eta_max) & (int)(q.re > 0.0) & (int)(fabs(S.eta.im) < P.fast_im_max));
+    return (S.eta.re <= P.fast_eta_max) & (q.re > 0.0) & (fabs(S.eta.im) < P.fast_im_max);
 }
 
 // z-independent part (after fast_eta said yes for every lane of the wave)
@@ -249,14 +260,17 @@ UCF_DEV void fast_common_terms(const ucf_dev_params& P, const lane_consts& L, do
         S.top = S.top3 = S.th;                                                                  // :78-79
     }
     if (FAMILY == 2) {
+        // |den| <= e^{maxexp} (1 + |xi|)(1 + beta |eta|) on the cosh/sinh form and <= that without the exponential on the
+        // other: with |xi| < 1e100 (make_lane_consts vouches for it, else the item is not taken) the reciprocal needs no
+        // exponent scaling
         const cplx xi = cmul(S.eta, L.xifac);                                                   // :70-75
         if (P.beta != 0.0) {
             const cplx one_bex = radd(1.0, cmul(rscale(P.beta, S.eta), xi));
-            if (S.small_eta) S.inv_den = cinv_auto(cadd(cmul(one_bex, S.che), cmul(xi, S.she)));  // :86-87
-            else S.inv_den = cinv_auto(cadd(one_bex, xi));                                        // :90-91
+            if (S.small_eta) S.inv_den = cinv_plain(cfma(one_bex, S.che, cmul(xi, S.she)));     // :86-87
+            else S.inv_den = cinv_plain(cadd(one_bex, xi));                                     // :90-91
         } else {                                                 // beta = 0 (wave-uniform): no product with (1, 0)
-            if (S.small_eta) S.inv_den = cinv_auto(cadd(S.che, cmul(xi, S.she)));
-            else S.inv_den = cinv_auto(radd(1.0, xi));
+            if (S.small_eta) S.inv_den = cinv_plain(cfma(xi, S.she, S.che));
+            else S.inv_den = cinv_plain(radd(1.0, xi));
         }
     }
     if (FAMILY == 4) {
@@ -374,8 +388,13 @@ UCF_DEV cplx fast_sample_z(const ucf_dev_params& P, const fast_common& S, int iz
         if (S.any_large && lay == 1) { const double c = 1.0 - zD; exz = expneg_direct(S.eta.re * c, S.eta.im * c, S.sc); }
     }
     const cplx top = (!FOLD && LAY3 && P.model != 4 && lay == 3) ? S.top3 : S.top;
-    if (S.small_eta) return csub(u, cmul(cmul(top, chz), S.inv_den));                           // :85-87
-    return csub(u, cmul(cmul(top, exz), S.inv_den));                                            // :89-91
+    // u - top (cosh(eta zD) | exp(eta (zD - 1))) / den  (:85-87 | :89-91); a wave that is on one form only (the usual case)
+    // does not select per lane
+    cplx g;
+    if (!S.any_large) g = chz;
+    else if (!S.any_small) g = exz;
+    else g = S.small_eta ? chz : exz;
+    return cfnma(cmul(top, g), S.inv_den, u);
 }
 
 }  // namespace UCF_NS

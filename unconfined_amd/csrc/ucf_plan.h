@@ -17,6 +17,7 @@ extern int ucf_finish_part;   /* diagnostic: lanes per scratch part in finish_ke
 struct ucf_dev_params {
     int model, MNtype, order, timeType, MoenchM;
     int M, np, k, N, R, nacc, ngl, nz;
+    int tab_premul;        // the abscissa table's Gauss-Lobatto entries carry their quadrature weight (fast flavour; abscissa_kernel)
     int nj0z, any_lay3;    // any_lay3: some depth of the launch (of any plan of a parameter batch) lies above the screen top
     int nz_out, z_off;     // depths of the whole call / offset of this launch's chunk: out index = pt*nz_out + z_off + z
     double timePar[2];
@@ -81,6 +82,13 @@ static inline void ucf_tm_mark(ucf_timers* tm, const char* name, void* stream)
     tm->open = 1;
 }
 
+// ucf_debug_stages: what the launcher did (one record per transform launch sequence of the call)
+struct ucf_debug_rec {
+    int count = 0;                 // launch sequences seen (the hook wants exactly one)
+    int layout = -1, nwork = 0, per_point = 0, nr = 0, nt = 0, ir0 = 0, nrc = 0, npts = 0;
+    double* d_totlap0 = nullptr;   // LAYOUT 0 keeps no transform: the hook lends it a buffer [npts][nz][np]
+};
+
 // Everything a call in flight writes.  A plan keeps one workspace per HIP stream that has called into it, so calls on
 // different streams never share scratch; calls that name the same stream are enqueued under the workspace's lock and
 // run in stream order.  Buffers only ever grow; a buffer that is outgrown is RETIRED (kept until ucf_plan_reserve /
@@ -102,6 +110,7 @@ struct ucf_workspace {
     ucf_buffer pblocks;            // parameter blocks of a parameter-batched launch (ucf_drawdown_multi)
     std::vector<void*> retired;    // outgrown buffers
     bool dry = false;              // ucf_plan_reserve: size the buffers, launch nothing
+    struct ucf_debug_rec* dbg = nullptr;   // ucf_debug_stages: the transform launches of the call in progress are recorded here
     ucf_timers tm = {};
     int tm_valid = 0;
     const char* tm_names[UCF_MAX_TIMED] = {};
@@ -130,6 +139,9 @@ struct ucf_plan {
     std::vector<ucf_workspace*> ws;
     ucf_workspace* last_timed = nullptr;
     long long n_alloc = 0;         // device allocations made on behalf of calls (ucf_plan_alloc_count)
+    // the stream of the host entry points that run asynchronously inside the library (ucf_drawdown_grid, ucf_drawdown_grid_multi):
+    // created on first use, destroyed with the plan -- a workspace is keyed by its stream, so the stream must outlive it
+    void* own_stream = nullptr;
 };
 
 // launchers implemented in ucf_kernels.hip (one set per build flavour)
@@ -142,7 +154,7 @@ int launch_expand_grid(int nt, int nr, const double* d_tD, const int* d_sv, cons
 int launch_points(const ucf_dev_params& dp, int npts, int per_point, int nr, int nsv, int svmin, const double* d_tD,
                   const double* d_rD, const int* d_sv, const double* d_tab, double* d_h, double* d_dh,
                   ucf_stats* d_stats, void* stream, double* d_glscr, double* d_state, int* d_ndone,
-                  const ucf_dev_params* d_params = nullptr, int ppp = 1, int pbase = 0);
+                  const ucf_dev_params* d_params = nullptr, int ppp = 1, int pbase = 0, double* d_dbg_totlap = nullptr);
 int launch_points_chunked(const ucf_dev_params& dp, int npts, int per_point, int nr, int nsv, int svmin, const double* d_tD,
                           const double* d_rD, const int* d_sv, const double* d_tab, double* d_totlap, double* d_h,
                           double* d_dh, ucf_stats* d_stats, void* stream, double* d_glscr, double* d_state, int* d_ndone,
@@ -161,6 +173,10 @@ int launch_dehoog(int n, int M, double alpha, double logtol, const double* d_t, 
                   const double* d_fp, double* d_ft, void* stream);
 int launch_wynn(int n, int nterms, const double* d_series, double* d_acc, int* d_status, void* stream);
 int launch_extrap(int n, int R, const double* d_x, const double* d_y, double* d_out, void* stream);
+int launch_debug_gather(const ucf_dev_params& dp, int layout, int nwork, int per_point, int nr, int nt, int ir0, const double* d_state,
+                        const int* d_ndone, double* d_out_state, int* d_out_ndone, void* stream);
+int launch_wynn_regs(int n, int nterms, const double* d_series, double* d_acc, int* d_status, void* stream);
+int launch_dehoog_tiles_hook(const ucf_dev_params& dp, int n, const double* d_tD, const double* d_totlap, double* d_h, double* d_dh, void* stream);
 }
 namespace ucf_fast {
 int launch_points_chunked(const ucf_dev_params& dp, int npts, int per_point, int nr, int nsv, int svmin, const double* d_tD,
@@ -173,7 +189,7 @@ int launch_grid_transposed(const ucf_dev_params& dp, int nt, int nr, int ir0, in
 int launch_points(const ucf_dev_params& dp, int npts, int per_point, int nr, int nsv, int svmin, const double* d_tD,
                   const double* d_rD, const int* d_sv, const double* d_tab, double* d_h, double* d_dh,
                   ucf_stats* d_stats, void* stream, double* d_glscr, double* d_state, int* d_ndone,
-                  const ucf_dev_params* d_params = nullptr, int ppp = 1, int pbase = 0);
+                  const ucf_dev_params* d_params = nullptr, int ppp = 1, int pbase = 0, double* d_dbg_totlap = nullptr);
 int launch_points_lanes(const ucf_dev_params& dp, int npts, int ppp, const double* d_tD, const double* d_rD, const int* d_sv,
                         const double* d_tab, double* d_totlap, double* d_h, double* d_dh, ucf_stats* d_stats, void* stream,
                         double* d_state, int* d_ndone, const ucf_dev_params* d_params = nullptr, int pbase = 0);
@@ -181,4 +197,6 @@ int launch_samples(const ucf_dev_params& dp, int n_a, const double* d_a, double 
                    void* stream);
 // bytes of integrate_kernel -> point_kernel state per work item (0 where the flavour / model has no integrate_kernel)
 size_t state_bytes_per_item(const ucf_dev_params& dp);
+int launch_wynn_regs(int n, int nterms, const double* d_series, double* d_acc, int* d_status, void* stream);
+int launch_dehoog_tiles_hook(const ucf_dev_params& dp, int n, const double* d_tD, const double* d_totlap, double* d_h, double* d_dh, void* stream);
 }

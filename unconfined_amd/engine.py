@@ -190,6 +190,14 @@ class Plan:
         _libmod.check(self._lib.ucf_drawdown_grid_shard_device(self._h, int(rank), int(world), int(nt), d_tD, d_sv, int(nr), d_rD,
                                                                len(zD), zD, zLay, d_h, d_dh, d_stats or None, stream or None))
 
+    def drawdown_grid_allgather(self, comm: int, rank: int, world: int, nt: int, d_tD: int, d_sv: int, nr: int, d_rD: int, zD, zLay,
+                                d_h: int, d_dh: int, stream: int = 0, d_stats: int = 0):
+        """this rank's rows, then the in-place RCCL all-gather of h and dh over `comm` (an ncclComm_t as an int:
+        comm_create() below or the host's own), all on `stream` (ucf_drawdown_grid_allgather)"""
+        zD, zLay = _f64(zD), _i32(zLay)
+        _libmod.check(self._lib.ucf_drawdown_grid_allgather(self._h, int(rank), int(world), int(nt), d_tD, d_sv, int(nr), d_rD,
+                                                            len(zD), zD, zLay, d_h, d_dh, d_stats or None, comm, stream or None))
+
     def drawdown_device(self, n: int, d_tD: int, d_rD: int, d_sv: int, zD, zLay, d_h: int, d_dh: int,
                         stream: int = 0, d_stats: int = 0):
         """asynchronous launch on device pointers (ints), e.g. torch tensors' data_ptr()"""
@@ -198,6 +206,26 @@ class Plan:
                                                           d_h, d_dh, d_stats or None, stream or None))
 
     # ---- stage hooks
+    def debug_stages(self, tD, sv, rD, zD, zLay, grid: bool = True):
+        """the intermediate stages of the PRODUCTION launch sequence (ucf_debug_stages): dict with
+        state [npts, np, R+1+nacc, nz] complex (level sums without arg/2 | running area | J0-interval areas), ndone [npts, np],
+        totlap [npts, nz, np] complex, h, dh [npts, nz], layout.  grid: nt times x nr radii, points in order it*nr + ir;
+        else a point list taken as ordered by radius"""
+        tD, sv, rD, zD, zLay = _f64(tD), _i32(sv), _f64(rD), _f64(zD), _i32(zLay)
+        nt, nr, nz = len(tD), len(rD), len(zD)
+        npts = nt * nr if grid else nt
+        D = self.derived
+        slots = (self.params.R + 1 + self.params.nacc) * nz
+        state = np.zeros((npts, D.np, slots, 2))
+        ndone = np.zeros((npts, D.np), np.int32)
+        totlap = np.zeros((npts, nz, D.np, 2))
+        h = np.zeros((npts, nz)); dh = np.zeros((npts, nz))
+        info = np.zeros(4, np.int32)
+        _libmod.check(self._lib.ucf_debug_stages(self._h, 1 if grid else 0, nt, tD, sv, nr, rD, nz, zD, zLay, state, ndone, totlap, h, dh, info))
+        st = (state[..., 0] + 1j * state[..., 1]).reshape(npts, D.np, self.params.R + 1 + self.params.nacc, nz)
+        return {"state": st, "has_state": bool(info[1]), "ndone": ndone, "totlap": totlap[..., 0] + 1j * totlap[..., 1], "h": h, "dh": dh,
+                "layout": int(info[0]), "R": self.params.R, "nacc": self.params.nacc}
+
     def lap_hank_soln(self, a, rD: float, p, zD, zLay) -> np.ndarray:
         """fp[n_a, nz, np, 2]"""
         a, p, zD, zLay = _f64(np.atleast_1d(a)), _f64(p), _f64(zD), _i32(zLay)
@@ -211,6 +239,26 @@ def shard_rows(nt: int, world: int, rank: int) -> Tuple[int, int]:
     lo, hi = C.c_int(0), C.c_int(0)
     _libmod.check(_libmod.load().ucf_shard_rows(int(nt), int(world), int(rank), C.byref(lo), C.byref(hi)))
     return lo.value, hi.value
+
+
+def comm_unique_id() -> bytes:
+    """128-byte id of a new RCCL communicator (rank 0 draws it and hands it to the other ranks: ucf_comm_unique_id)"""
+    buf = C.create_string_buffer(128)
+    _libmod.check(_libmod.load().ucf_comm_unique_id(buf))
+    return buf.raw
+
+
+def comm_create(unique_id: bytes, world: int, rank: int) -> int:
+    """RCCL communicator of the library's own on the current HIP device (ucf_comm_create); returns the handle"""
+    if len(unique_id) != 128:
+        raise ValueError("the unique id has 128 bytes")
+    h = C.c_void_p()
+    _libmod.check(_libmod.load().ucf_comm_create(unique_id, int(world), int(rank), C.byref(h)))
+    return h.value
+
+
+def comm_destroy(comm: int) -> None:
+    _libmod.check(_libmod.load().ucf_comm_destroy(comm))
 
 
 def build_id() -> str:
@@ -259,6 +307,24 @@ def drawdown_multi(plans, t, r, z, dimensionless: bool = False):
     h = np.zeros((npl, n, nz))
     dh = np.zeros((npl, n, nz))
     _libmod.check(lib.ucf_drawdown_multi(arr, npl, n, t, r, nz, z, 1 if dimensionless else 0, h, dh))
+    return h, dh
+
+
+def debug_wynn(series, mode: str = "faithful"):
+    """wynn_epsilon as finish_kernel runs it (epsilon table in registers, at most 12 terms): acc [n, 2], status [n]"""
+    series = _f64(series)
+    n, nterms = series.shape[0], series.shape[1]
+    acc = np.zeros((n, 2)); st = np.zeros(n, np.int32)
+    _libmod.check(_libmod.load().ucf_debug_wynn(1 if mode == "fast" else 0, n, nterms, series, acc, st))
+    return acc, st
+
+
+def debug_dehoog_tiles(M: int, alpha: float, tol: float, t, fp, mode: str = "faithful"):
+    """deHoog_invlap as every grid call runs it (dehoog_tiles_kernel): fp [n, 2M+1, 2], T = 2 t; returns h [n], dh [n]"""
+    t, fp = _f64(np.atleast_1d(t)), _f64(fp)
+    n = len(t)
+    h = np.zeros(n); dh = np.zeros(n)
+    _libmod.check(_libmod.load().ucf_debug_dehoog_tiles(1 if mode == "fast" else 0, n, int(M), float(alpha), float(tol), t, fp, h, dh))
     return h, dh
 
 

@@ -28,10 +28,12 @@ EXPORTS = [
     "ucf_plan_gauss_lobatto", "ucf_plan_set_mode", "ucf_plan_set_timing", "ucf_plan_kernel_ms", "ucf_plan_kernel_times",
     "ucf_plan_reserve", "ucf_plan_alloc_count", "ucf_build_id",
     "ucf_shard_rows", "ucf_drawdown_grid_shard_device", "ucf_drawdown_grid_multi", "ucf_drawdown_batch_multi",
+    "ucf_drawdown_grid_allgather", "ucf_comm_unique_id", "ucf_comm_create", "ucf_comm_destroy",
     "ucf_logspace", "ucf_linspace", "ucf_zlay", "ucf_split_vector",
     "ucf_drawdown_batch", "ucf_drawdown_batch_device", "ucf_drawdown_grid", "ucf_drawdown_grid_device",
     "ucf_drawdown_multi", "ucf_screen_average",
     "ucf_eval_samples", "ucf_pvalues", "ucf_dehoog", "ucf_wynn_epsilon", "ucf_extraptozero", "ucf_bessel_k01",
+    "ucf_debug_stages", "ucf_debug_wynn", "ucf_debug_dehoog_tiles",
     "ucf_fp64_fma_peak", "ucf_sincos_table", "ucf_exp2_table",
 ]
 
@@ -91,6 +93,10 @@ def load() -> C.CDLL:
     lib.ucf_build_id.restype = C.c_char_p
     lib.ucf_shard_rows.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.ucf_drawdown_grid_shard_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp, C.c_int, _dp, _ip, vp, vp, vp, vp]
+    lib.ucf_drawdown_grid_allgather.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp, C.c_int, _dp, _ip, vp, vp, vp, vp, vp]
+    lib.ucf_comm_unique_id.argtypes = [C.c_char_p]
+    lib.ucf_comm_create.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(vp)]
+    lib.ucf_comm_destroy.argtypes = [vp]
     lib.ucf_drawdown_grid_multi.argtypes = [C.POINTER(vp), C.c_int, C.c_int, _dp, _ip, C.c_int, _dp, C.c_int, _dp, _ip, _dp, _dp,
                                             C.POINTER(UcfStats)]
     lib.ucf_drawdown_batch_multi.argtypes = [C.POINTER(vp), C.c_int, C.c_int, _dp, _dp, _ip, C.c_int, _dp, _ip, _dp, _dp, C.POINTER(UcfStats)]
@@ -110,6 +116,9 @@ def load() -> C.CDLL:
     lib.ucf_wynn_epsilon.argtypes = [C.c_int, C.c_int, _dp, _dp, _ip]
     lib.ucf_extraptozero.argtypes = [C.c_int, C.c_int, _dp, _dp, _dp]
     lib.ucf_bessel_k01.argtypes = [C.c_int, _dp, _dp, _ip]
+    lib.ucf_debug_stages.argtypes = [vp, C.c_int, C.c_int, _dp, _ip, C.c_int, _dp, C.c_int, _dp, _ip, _dp, _ip, _dp, _dp, _dp, _ip]
+    lib.ucf_debug_wynn.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp, _ip]
+    lib.ucf_debug_dehoog_tiles.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, _dp, _dp, _dp, _dp]
     lib.ucf_fp64_fma_peak.argtypes = [C.POINTER(C.c_double)]
     lib.ucf_sincos_table.argtypes = [C.POINTER(C.c_double)]
     lib.ucf_exp2_table.argtypes = [C.POINTER(C.c_double)]
