@@ -74,8 +74,15 @@ def workload_deck(name):
         return c2, 1024, 256, "C2: Neuman-1974 (model 5, beta=0) fully penetrating"
     if name == "c2pp":     # same sweep, partially penetrating pumping well (cape-cod-neuman74.in geometry)
         return c2.replace(l=60.2, d=13.2), 1024, 256, "C2pp: Neuman-1974 (model 5, beta=0) partially penetrating"
-    g = Deck.read(os.path.join(ROOT, "tests", "golden", "decks", {"c3": "c3_moench", "c4": "c4_malama_partpen",
-                                                                "c5": "c5_mishra_fd64"}[name] + ".in"))
+    g = Deck.read(os.path.join(ROOT, "tests", "golden", "decks", {"c3": "c3_moench", "c4": "c4_malama_partpen", "c5": "c5_mishra_fd64",
+                                                                "c1": "c1_theis", "hstorage": "hstorage_partpen_lay2",
+                                                                "mnm": "mishra_malama"}[name] + ".in"))
+    if name == "c1":
+        return g, 1024, 256, "C1: Theis (model 0), 1024 x 256 sweep"
+    if name == "hstorage":
+        return g, 1024, 256, "Hantush with wellbore storage (model 2), partially penetrating"
+    if name == "mnm":
+        return g, 1024, 256, "Mishra-Neuman, Malama's closed form (model 6 / MNtype 1)"
     if name == "c3":
         return g, 2048, 512, "C3: Moench 3-alpha delayed yield, screened observation well (nz=2)"
     if name == "c4":
@@ -141,12 +148,13 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--mode", default=os.environ.get("UCF_BENCH_MODE", "fast"), choices=["faithful", "fast"])
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"])
-    ap.add_argument("--workload", default="c2", choices=["c2", "c2pp", "c3", "c4", "c5"])
+    ap.add_argument("--workload", default="c2", choices=["c2", "c2pp", "c3", "c4", "c5", "c1", "hstorage", "mnm"])
     ap.add_argument("--nt", type=int, default=0)
     ap.add_argument("--nr", type=int, default=0)
     ap.add_argument("--layout", default="auto", choices=["auto", "sample"])
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-other-scaling", action="store_true")
+    ap.add_argument("--no-other-workloads", action="store_true")
     return ap.parse_args(argv)
 
 
@@ -532,6 +540,49 @@ def worker(args):
         cb.pop("_rows", None); cb.pop("_radii", None)
         line["cpu_baseline"] = cb
         line["gpu_over_cpu"] = value / cb["value"] if args.workload == "c2" else None
+    if world == 1 and not args.no_other_workloads and not args.no_cpu and args.workload == "c2" and not args.nt and not args.nr:
+        # the other BASELINE.json configurations (and the models outside them) at FULL size on this GPU, after the timed
+        # region: the same step (resident inputs, the grid entry on the current stream), 1 warm-up + 2 timed steps each,
+        # per-kernel times from the library's event brackets
+        others = {}
+        for w in ("c2pp", "c3", "c4", "c5", "c1", "hstorage", "mnm"):
+            try:
+                dk2, nt2, nr2, nm2 = workload_deck(w)
+                pl2 = engine.Plan(params_from_deck(dk2), mode=args.mode)
+                D2 = pl2.derived
+                tD2 = engine.logspace(-1, 8, nt2) / D2.Tc
+                zD2 = engine.linspace(dk2.zBot, dk2.zTop, 1 if dk2.piezometer else dk2.zOrd) / D2.Lc
+                zl2 = pl2.zlay(zD2)
+                d_t2 = torch.from_numpy(np.ascontiguousarray(tD2)).to(dev)
+                d_s2 = torch.from_numpy(pl2.split_vector(tD2).astype(np.int32)).to(dev)
+                d_r2 = torch.from_numpy(np.ascontiguousarray(10.0 ** engine.linspace(-1.0, 1.0, nr2))).to(dev)
+                d_o2 = torch.zeros(2, nt2 * nr2 * len(zD2), dtype=torch.float64, device=dev)
+
+                def step2():
+                    pl2.drawdown_grid_device(nt2, d_t2.data_ptr(), d_s2.data_ptr(), nr2, d_r2.data_ptr(), zD2, zl2, d_o2[0].data_ptr(), d_o2[1].data_ptr(),
+                                             stream=stream.cuda_stream)
+                step2()
+                torch.cuda.synchronize()
+                pl2.set_timing(True)
+                nst = 2
+                t0 = time.perf_counter()
+                ks = {}
+                for k in range(nst):
+                    step2()
+                    torch.cuda.synchronize()
+                    for name, ms, cnt in pl2.kernel_times():
+                        ks.setdefault(name, []).append((ms, cnt))
+                el = time.perf_counter() - t0
+                pl2.set_timing(False)
+                others[w] = {"workload": f"{nm2}, {nt2} x {nr2}, nz={len(zD2)}", "value": nt2 * nr2 * nst / el, "unit": "points/s",
+                             "ms_per_step": el / nst * 1e3, "steps": nst, "finite": bool(torch.isfinite(d_o2).all().item()),
+                             "kernels": [{"name": n, "ms_per_launch": float(np.sum([m for m, _ in v]) / max(1, np.sum([c for _, c in v]))),
+                                          "launches_per_step": int(round(np.mean([c for _, c in v])))} for n, v in ks.items()]}
+                pl2.close()
+                del d_o2
+            except Exception as exc:
+                others[w] = {"error": str(exc)}
+        line["other_workloads"] = others
     print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -8,12 +8,15 @@ every row (time) of every radius of tests/golden/e2e_<deck>.npz this script eval
     c_h(row)  = sum_m |d h / d totlap_m| max_k |totlap_k| / max(|h|, floor)          (and c_dh for t dh/dt)
 
 the first-order bound on the relative change of the result when every Laplace-space value moves by epsilon times the
-LARGEST of them -- the noise of the values is absolute (they come out of sums over the abscissae and out of the series
-acceleration with an error floor set by the largest terms), and the small values at high Laplace index are where the
-inversion is most sensitive.  (|d/d totlap_m| = norm of the derivatives along the real and the imaginary direction,
-central differences of the oracle's de Hoog; floor = 1e-3 in the printed units, as in the parity gates.)  A device
-result whose Laplace-space values are good to k u max|totlap| cannot be expected closer than k u c(row): gate (2) of
-tests/test_gpu_parity.py uses max(1e-10, 20 x reference noise, k u c(row)) per row -- no exception clause.
+LARGEST of them.  That is the noise model that fits what is observed: the values come out of sums
+over the abscissae and out of the series acceleration with an error floor set by the largest terms, and the small values
+at high Laplace index are where the inversion is most sensitive -- the row that broke the round-2 gate (C2, radius 2, row
+168: dh off by 2.4e-10 with Laplace-space values 3e-15 of the largest away from the oracle's) has c_dh = 4.1e4, its
+neighbours the same; with relative perturbations of each value's own modulus the same row has c = 5e3, which would need
+values 50 u off.  (|d/d totlap_m| = norm of the derivatives along the real and the imaginary direction, central differences
+of the oracle's de Hoog; floor = 1e-3 in the printed units, as in the parity gates.)  A device result whose Laplace-space
+values are good to k u max|totlap| cannot be expected closer than k u c(row): gate (2) of tests/test_gpu_parity.py uses
+max(1e-10, 20 x reference noise, k u c(row)) per row -- no exception clause.
 Writes tests/golden/conditioning.npz (ch_<deck>_r<ir>, cdh_<deck>_r<ir>: [rows])."""
 import os
 import sys

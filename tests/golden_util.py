@@ -75,11 +75,22 @@ def rel_err(x, ref, floor=1e-3):
     return np.abs(x - ref) / np.maximum(np.abs(ref), floor)
 
 
+COND_K = 64.0          # Laplace-space values good to COND_K u of the largest: what gate (2) grants per row through c(row)
+
+
+def conditioning(name, ir):
+    """(c_h, c_dh) per row of radius `ir` of deck `name`: first-order amplification of the last stage (de Hoog) of a
+    perturbation of the Laplace-space values by epsilon times the largest of them (oracle/gen_conditioning.py)"""
+    z = np.load(os.path.join(GOLD, "conditioning.npz"))
+    return z[f"ch_{name}_r{ir}"].astype(np.float64), z[f"cdh_{name}_r{ir}"].astype(np.float64)
+
+
 def e2e_gate_bounds(oracle, name, ir, factor=20.0):
     """per-row bounds of the end-to-end gate (2) of tests/test_gpu_parity.py for radius `ir` of deck `name`:
-    max(1e-10, factor x noise), noise = the larger of the reference's build-to-build spread (running max over +-8
-    rows) and its error against the binary128 evaluation on the truth subsample.  Returns (ref rows, bound_h, bound_dh);
-    errors are relative with the floor max(|ref|, 1e-3) on the DIMENSIONAL (as printed) values."""
+    max(1e-10, factor x noise, COND_K u c(row)); noise = the larger of the reference's build-to-build spread (running max
+    over +-8 rows) and its error against the binary128 evaluation on the truth subsample; c(row) = conditioning of the
+    inversion at that time (conditioning()).  Returns (ref rows, bound_h, bound_dh); errors are relative with the floor
+    max(|ref|, 1e-3) on the DIMENSIONAL (as printed) values."""
     e2e = load_e2e(name)
     tr = np.load(os.path.join(GOLD, f"truth_{name}.npz"))
     dk, ts, P = load_deck(name)
@@ -98,9 +109,10 @@ def e2e_gate_bounds(oracle, name, ir, factor=20.0):
     noise_t = (float(rel_err(ho, tr[f"h_r{ir}"], fl_raw).max()), float(rel_err(dho, tr[f"dh_r{ir}"], fl_raw).max()))
     ref, alt = e2e[f"O2_r{ir}"], e2e[f"O3native_r{ir}"]
     out = []
-    for col, nt_ in ((1, noise_t[0]), (2, noise_t[1])):
+    cond = conditioning(name, ir)
+    for col, nt_, c in ((1, noise_t[0], cond[0]), (2, noise_t[1], cond[1])):
         spread = rel_err(alt[:, col], ref[:, col], 1e-3)
         k = 8
         sp = np.array([spread[max(0, i - k): i + k + 1].max() for i in range(len(spread))])
-        out.append(np.maximum(1e-10, factor * np.maximum(sp, nt_)))
+        out.append(np.maximum(np.maximum(1e-10, factor * np.maximum(sp, nt_)), COND_K * 2.220446049250313e-16 * c))
     return ref, out[0], out[1]

@@ -348,11 +348,17 @@ def test_fuzz_regressions_layer3_series_stay_clean(engine):
 
 
 def test_far_field_points_keep_their_accuracy(engine, oracle, oracle_quad):
-    """two points of tools/fuzz_hunt.py (seed 903 set 26, seed 700 set 39) at which a faster form of the water-table sample --
-    one reciprocal 1 / (q den) for both the theis term and the closure term -- was 2e-6 / 4e-6 off while the reference is good
-    to 7e-10 / 9e-8: at larger radii the Hankel integral of the theis term cancels to a fraction of its intervals and wants
-    1 / q as a term of its own.  The fast flavour must stay within 20x of the reference's own distance
-    from the binary128 value there (the rejected form: 3 300x and 46x)."""
+    """two far-field points of tools/fuzz_hunt.py (seed 903 set 26, seed 700 set 39) at which an evaluator variant of round 2
+    -- one reciprocal 1 / (q den) for the theis term and the closure term -- looked 1000x worse than the reference while its
+    samples were as good as any.  Round 3 found why (tools/dbg_single_rcp.py): at these points the result
+    of the reference ALGORITHM in binary64 is bimodal.  De Hoog's improved remainder (invlap.f90:120-125) takes the complex
+    square root of 1 + d(2M) z / brem^2; here that argument has a negative real part (-3 ... -4) and an imaginary part (+-1)
+    made of the last two continued-fraction coefficients -- the most noise-amplified entries of the quotient-difference
+    table -- whose SIGN changes with the last bits of the Laplace-space values: the argument crosses the branch cut of the
+    square root and the result jumps by the size of the remainder term, 3e-6 at the first point.  The reference lands on the
+    far branch in 7 of 12 copies of the point with tD moved by k x 1e-13 (error 3e-6 against binary128 instead of 1e-9); which
+    branch a given build takes at the recorded tD is a coin toss, for the device as for the CPU.  What can be asked is that
+    the device's WORST error over 24 such copies stays within 4x the reference's worst."""
     import os, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.join(root, "tools"))
@@ -362,16 +368,17 @@ def test_far_field_points_keep_their_accuracy(engine, oracle, oracle_quad):
         for i, bname, ch, tD, rD, zD in fuzz_hunt.sets_of(seed, nset, 320):
             pass
         P = params_from_deck(load_deck(bname)[0].replace(**ch))
-        q = int(np.argmin(np.abs(tD - tq) + np.abs(rD - rq)))
-        assert tD[q] == tq and rD[q] == rq
-        plan = engine.Plan(P, mode="fast")
-        zl = plan.zlay(zD); sv = plan.split_vector(tD)
-        sl = slice(q, q + 1)
-        h, _ = plan.drawdown(tD[sl], rD[sl], sv[sl], zD, zl)
-        ho, _ = oracle.batch(P, tD[sl], rD[sl], sv[sl], zD, zl)
-        ht, _ = oracle_quad.batch(P, tD[sl], rD[sl], sv[sl], zD, zl)
-        e_fast, e_ref = np.abs(h[0] - ht[0]) / np.abs(ht[0]), np.abs(ho[0] - ht[0]) / np.abs(ht[0])
-        assert (e_fast <= 20.0 * np.maximum(e_ref, 1e-12)).all(), (seed, e_fast.tolist(), e_ref.tolist())
+        tds = tq * (1.0 + np.arange(24) * 1e-13)
+        rds = np.full(24, rq)
+        for mode in ("fast", "faithful"):
+            plan = engine.Plan(P, mode=mode)
+            zl = plan.zlay(zD); sv = plan.split_vector(tds)
+            h, _ = plan.drawdown(tds, rds, sv, zD, zl)
+            ho, _ = oracle.batch(P, tds, rds, sv, zD, zl)
+            ht, _ = oracle_quad.batch(P, tds, rds, sv, zD, zl, threads=8)
+            e_dev, e_ref = np.abs(h - ht) / np.abs(ht), np.abs(ho - ht) / np.abs(ht)
+            for z in range(len(zD)):
+                assert e_dev[:, z].max() <= 4.0 * max(e_ref[:, z].max(), 1e-12), (seed, mode, z, float(e_dev[:, z].max()), float(e_ref[:, z].max()))
 
 
 @pytest.mark.parametrize("mode", ["fast", "faithful"])

@@ -15,16 +15,22 @@ Bars (the reference is fp64; see DESIGN.md "Parity"):
               max err_gpu <= max(1e-10, 10 x max err_ref),  median err_gpu <= max(2e-12, 20 x median err_ref)
               (50 x for the finite-difference Mishra-Neuman model, whose Thomas recursion amplifies);
       (2) against every row of the reference binary's .out:
-              |gpu - ref| <= max(1e-10, 20 x noise), noise = the larger of the reference's
-              build-to-build spread (running max over +-8 times) and its error against (1);
+              |gpu - ref| <= max(1e-10, 20 x noise, 64 u c(row)), noise = the larger of the reference's
+              build-to-build spread (running max over +-8 times) and its error against (1); c(row) = the
+              conditioning of the last stage at that time: the first-order amplification, by de Hoog's inversion,
+              of a perturbation of the 2M+1 Laplace-space values by epsilon x the largest of them
+              (tests/golden/conditioning.npz, oracle/gen_conditioning.py) -- a device whose Laplace-space values are
+              good to 64 u cannot be asked for more than 64 u c(row).  EVERY row, no exception clause;
           for the headline C2 configuration additionally >= 95 % of all points within 1e-10 in h.
+    Both gates run through the point-list entry (lane = point / lane = Laplace sample) for every deck and, for the four
+    BASELINE decks, through the GRID entry as well (lane = time: the layout bench.py measures).
 """
 import os
 
 import numpy as np
 import pytest
 
-from golden_util import (GOLD, bits_equal, crel, deck_names, load_deck, load_e2e, load_stages, rel_err, ulps)
+from golden_util import (COND_K, GOLD, bits_equal, conditioning, crel, deck_names, load_deck, load_e2e, load_stages, rel_err, ulps)
 
 pytestmark = pytest.mark.gpu
 
@@ -196,18 +202,54 @@ def _truth(name):
     return np.load(p) if os.path.exists(p) else None
 
 
+BASELINE_DECKS = ["c2_neuman74_fullpen", "c3_moench", "c4_malama_partpen", "c5_mishra_fd64"]
+ENTRIES = [(n, "list") for n in NAMES] + [(n, "grid") for n in BASELINE_DECKS]
+
+
+def _layout_of_last_timed_call(plan):
+    """lane layout of the transform kernel of the last grid call (second template argument of its name)"""
+    import re
+    for name, ms, cnt in plan.kernel_times():
+        m = re.search(r"integrate(?:_generic)?_kernel<\d+, (\d+)", name) or re.search(r"point_kernel<\d+, (\d+)", name)
+        if m:
+            return int(m.group(1))
+    return -1
+
+
+def _through_grid(plan, tD, sv, rDs, zD, zl, with_stats=False):
+    """all times x all radii of a fixture through the GRID entry in the lane = time layout (LAYOUT 1): the time vector is
+    padded to a multiple of 64 (the padding rows are dropped), which is what makes the library pick that layout for the
+    100- to 256-row fixtures as it does for the 1024-row sweeps; the layout that ran is read back from the kernel names"""
+    nt = len(tD)
+    pad = (-nt) % 64
+    tDp = np.concatenate([tD, np.full(pad, tD[-1])])
+    svp = np.concatenate([sv, np.full(pad, sv[-1], sv.dtype)])
+    plan.set_timing(True)
+    out = plan.drawdown_grid(tDp, svp, rDs, zD, zl, with_stats=with_stats)
+    assert _layout_of_last_timed_call(plan) == 1, "the grid entry did not run the lane = time layout"
+    plan.set_timing(False)
+    return (out[0][:nt], out[1][:nt]) + tuple(out[2:])
+
+
 @pytest.mark.parametrize("mode", MODES)
-@pytest.mark.parametrize("name", NAMES)
-def test_end_to_end_vs_binary128_truth(engine, oracle, name, mode):
+@pytest.mark.parametrize("name,entry", ENTRIES)
+def test_end_to_end_vs_binary128_truth(engine, oracle, name, entry, mode):
     """gate (1): the device result is as close to the exact-arithmetic evaluation of the reference
     algorithm as the (bit-pinned) binary64 oracle, i.e. the reference, is"""
     e2e, tr = load_e2e(name), _truth(name)
     assert e2e is not None and tr is not None
     idx = tr["idx"]
+    grid_res = None
+    if entry == "grid":
+        dk, P, D, t, tD, rD, sv, zD, zl = _grid(oracle, name, 0, e2e)
+        grid_res = _through_grid(engine.Plan(P, mode=mode), tD, sv, e2e["radii"] / D.Lc, zD, zl)
     for ir in range(len(e2e["radii"])):
         dk, P, D, t, tD, rD, sv, zD, zl = _grid(oracle, name, ir, e2e)
-        plan = engine.Plan(P, mode=mode)
-        h, dh = plan.drawdown(tD[idx], rD[idx], sv[idx], zD, zl)
+        if entry == "grid":
+            h, dh = grid_res[0][idx, ir, :], grid_res[1][idx, ir, :]
+        else:
+            plan = engine.Plan(P, mode=mode)
+            h, dh = plan.drawdown(tD[idx], rD[idx], sv[idx], zD, zl)
         ho, dho = oracle.batch(P, tD[idx], rD[idx], sv[idx], zD, zl)
         floor = 1e-3 / (1.0 if dk.dimless else D.Hc)
         for got, ref, truth, label in ((h, ho, tr[f"h_r{ir}"], "h"), (dh, dho, tr[f"dh_r{ir}"], "dh")):
@@ -216,24 +258,31 @@ def test_end_to_end_vs_binary128_truth(engine, oracle, name, mode):
             # the max over ~100 points of a 1e5..1e7x amplified rounding error is heavy-tailed: the fast flavour
             # (different roundings in exp/sincos/sqrt) gets 20x the reference's own worst point, the faithful one 10x
             fmax = 10.0 if mode == "faithful" else 20.0
-            _record("vs_binary128_truth", name, mode, label + "_max", eg.max() / max(1e-10, fmax * er.max()), err=eg.max(), ref_err=er.max())
-            _record("vs_binary128_truth", name, mode, label + "_median", np.median(eg) / max(2e-12, fmed * np.median(er)), err=np.median(eg))
+            _record("vs_binary128_truth", name + ("" if entry == "list" else "@grid"), mode, label + "_max", eg.max() / max(1e-10, fmax * er.max()), err=eg.max(), ref_err=er.max())
+            _record("vs_binary128_truth", name + ("" if entry == "list" else "@grid"), mode, label + "_median", np.median(eg) / max(2e-12, fmed * np.median(er)), err=np.median(eg))
             assert eg.max() <= max(1e-10, fmax * er.max()), (name, mode, ir, label, float(eg.max()), float(er.max()))
             assert np.median(eg) <= max(2e-12, fmed * np.median(er)), (name, mode, ir, label, float(np.median(eg)), float(np.median(er)))
 
 
 @pytest.mark.parametrize("mode", MODES)
-@pytest.mark.parametrize("name", NAMES)
-def test_end_to_end_vs_reference_outputs(engine, oracle, name, mode):
+@pytest.mark.parametrize("name,entry", ENTRIES)
+def test_end_to_end_vs_reference_outputs(engine, oracle, name, entry, mode):
     """gate (2): the whole loop body (a1) against every row of the reference binary's own .out"""
     from unconfined_amd.host import screen_average_np
     e2e, tr = load_e2e(name), _truth(name)
     assert e2e is not None
     frac_ok = []
+    grid_res = None
+    if entry == "grid":
+        dk, P, D, t, tD, rD, sv, zD, zl = _grid(oracle, name, 0, e2e)
+        grid_res = _through_grid(engine.Plan(P, mode=mode), tD, sv, e2e["radii"] / D.Lc, zD, zl)
     for ir in range(len(e2e["radii"])):
         dk, P, D, t, tD, rD, sv, zD, zl = _grid(oracle, name, ir, e2e)
-        plan = engine.Plan(P, mode=mode)
-        h, dh, st = plan.drawdown(tD, rD, sv, zD, zl, with_stats=True)
+        if entry == "grid":
+            h, dh = grid_res[0][:, ir, :], grid_res[1][:, ir, :]
+        else:
+            plan = engine.Plan(P, mode=mode)
+            h, dh, st = plan.drawdown(tD, rD, sv, zD, zl, with_stats=True)
         sc = 1.0 if dk.dimless else D.Hc
         hobs, dobs = screen_average_np(h, dk) * sc, screen_average_np(dh, dk) * sc
         ref, alt = e2e[f"O2_r{ir}"], e2e[f"O3native_r{ir}"]
@@ -243,24 +292,20 @@ def test_end_to_end_vs_reference_outputs(engine, oracle, name, mode):
         ho, dho = oracle.batch(P, tD[idx], rD[idx], sv[idx], zD, zl)
         fl_raw = 1e-3 / sc
         noise_t = {"h": float(rel_err(ho, tr[f"h_r{ir}"], fl_raw).max()), "dh": float(rel_err(dho, tr[f"dh_r{ir}"], fl_raw).max())}
+        cond = dict(zip(("h", "dh"), conditioning(name, ir)))
         for col, got, label in ((1, hobs, "h"), (2, dobs, "dh")):
             err = rel_err(got, ref[:, col], floor)
             spread = rel_err(alt[:, col], ref[:, col], floor)
             k = 8
             sp = np.array([spread[max(0, i - k): i + k + 1].max() for i in range(len(spread))])
-            bound = np.maximum(1e-10, 20.0 * np.maximum(sp, noise_t[label]))
+            # per row: the reference's own noise around that time, or what the conditioning of the inversion at that time makes
+            # of Laplace-space values that are good to COND_K u (of the largest of them) -- whichever is larger.  Every row.
+            bound = np.maximum(np.maximum(1e-10, 20.0 * np.maximum(sp, noise_t[label])), COND_K * 2.220446049250313e-16 * cond[label])
             bad = err > bound
-            # One isolated row per series of >= 512 rows may exceed its bound by < 3x.  At single times de Hoog's inversion
-            # amplifies a 1e-15 pattern in the Laplace-space values by 1e5 (the reference's own -O2 / -O3 outputs show it, e.g.
-            # row 166 of radius 0 of the C2 fixture: 4e-8 in dh); which pattern hits such a row changes with the roundings.
-            # tools/dbg_stage.py c2_neuman74_fullpen 2 168: the fast flavour's Laplace-space values are within 3e-15 of the
-            # oracle's, no in-band rule fires, and inverting exactly those values in binary128 gives the same 2.4e-10 in dh
-            # (neighbours 1e-12, h 3e-14).  Recorded as n_over.
-            allowed = 1 if (mode == "fast" and len(err) >= 512) else 0
-            ok = (not bad.any()) or (int(bad.sum()) <= allowed and float((err / bound).max()) < 3.0)
-            _record("vs_reference_out", name, mode, label, (err / bound).max(), err=err.max(), frac_within_1e_10=np.mean(err <= 1e-10),
-                    n_over=int(bad.sum()))
-            assert ok, (name, mode, ir, label, float(err.max()), float(spread.max()), noise_t[label], int(bad.sum()))
+            _record("vs_reference_out", name + ("" if entry == "list" else "@grid"), mode, label, (err / bound).max(), err=err.max(),
+                    frac_within_1e_10=np.mean(err <= 1e-10), n_over=int(bad.sum()),
+                    rows_ruled_by_conditioning=int((COND_K * 2.220446049250313e-16 * cond[label] > np.maximum(1e-10, 20.0 * np.maximum(sp, noise_t[label]))).sum()))
+            assert not bad.any(), (name, entry, mode, ir, label, float(err.max()), float((err / bound).max()), int(np.argmax(err / bound)), int(bad.sum()))
             if label == "h":
                 frac_ok.append(float(np.mean(err <= 1e-10)))
     if name == "c2_neuman74_fullpen":
@@ -329,6 +374,8 @@ def test_full_size_properties(engine, oracle):
     idx = np.arange(0, nt * nr, 4099)
     ho, dho = oracle.batch(P, TT.ravel()[idx], RR.ravel()[idx], sv[idx], zD, zl)
     assert rel_err(h[idx], ho, 1e-3 / D.Hc).max() < 5e-10
+    # (dh: the inversion of p F(p) is 100 x worse conditioned than that of F(p), tests/golden/conditioning.npz)
+    assert rel_err(dh[idx], dho, 1e-3 / D.Hc).max() < 5e-8
     # linearity / superposition through the time-behaviour multiplier (time.f90:47-52)
     T = 50.0
     from unconfined_amd.abi import params_from_deck
@@ -343,6 +390,72 @@ def test_full_size_properties(engine, oracle):
     late = TT.ravel()[sub] > 4.0 * T
     dev = np.abs(lhs - h_pulse)[late] / np.maximum(np.abs(h[sub][late]), 1e-3 / D.Hc)
     assert dev.max() < 1e-4, float(dev.max())
+
+
+@pytest.mark.parametrize("name,nt,nr", [("c3_moench", 2048, 512), ("c4_malama_partpen", 4096, 1024), ("c5_mishra_fd64", 1024, 256)])
+def test_full_size_properties_other_configs(engine, oracle, oracle_quad, name, nt, nr):
+    """BASELINE.json's configs 3-5 at FULL size through the grid entry (lane = time, radii in chunks: what bench.py
+    --workload c3|c4|c5 runs), fast flavour, through size-independent properties: (1) finite everywhere, no in-band rule
+    fired; (2) drawdown does not decrease in time at fixed radius nor increase with radius at fixed time where it is
+    resolved -- EXCEPT at the isolated points where the reference's own algorithm breaks that (its series acceleration
+    produces blips in exact arithmetic too, e.g. C3 at tD = 0.335, rD = 0.634: 0.2286 between 0.3056 and 0.3073): there are
+    few of them (< 1e-4 of the sweep) and at every one the device reproduces the ORACLE's value; (3) the chunking of the
+    radii does not change a bit (a column block computed on its own); (4) a strided subsample against the oracle, h and dh;
+    (5) the faithful flavour on a sub-grid agrees with the fast one."""
+    dk, ts, P = load_deck(name)
+    plan = engine.Plan(P, mode="fast")
+    D = plan.derived
+    tD = engine.logspace(-1, 8, nt) / D.Tc
+    rD = 10.0 ** engine.linspace(-1.0, 1.0, nr)
+    sv = plan.split_vector(tD)
+    zD = engine.linspace(dk.zBot, dk.zTop, 1 if dk.piezometer else dk.zOrd) / D.Lc
+    zl = plan.zlay(zD)
+    hg, dhg, st = plan.drawdown_grid(tD, sv, rD, zD, zl, with_stats=True)
+    assert np.isfinite(hg).all() and np.isfinite(dhg).all()
+    assert st["wynn_sentinel"] == 0 and st["nan_scrubbed"] == 0 and st["wynn_truncated"] == 0
+    floor = 1e-3 / D.Hc
+    suspects = set()
+    for z in range(len(zD)):
+        H = hg[:, :, z]
+        tol = 2e-6 * np.maximum(np.abs(H), 5.0)
+        resolved = (H[1:] > 1e-3) & (H[:-1] > 1e-3)
+        for i, j in np.argwhere((np.diff(H, axis=0) < -tol[1:]) & resolved):
+            suspects |= {(int(i), int(j)), (int(i) + 1, int(j))}
+        resolved_r = (H[:, 1:] > 1e-3) & (H[:, :-1] > 1e-3)
+        for i, j in np.argwhere((np.diff(H, axis=1) > tol[:, 1:]) & resolved_r):
+            suspects |= {(int(i), int(j)), (int(i), int(j) + 1)}
+    assert len(suspects) <= max(4, 1e-4 * nt * nr), ("too many non-monotone points", name, len(suspects))
+    if suspects:
+        sp = np.array(sorted(suspects))[:160]
+        ho, dho = oracle.batch(P, tD[sp[:, 0]], rD[sp[:, 1]], sv[sp[:, 0]], zD, zl)
+        hq, dhq = oracle_quad.batch(P, tD[sp[:, 0]], rD[sp[:, 1]], sv[sp[:, 0]], zD, zl, threads=8)
+        e_dev = rel_err(hg[sp[:, 0], sp[:, 1]], ho, floor).max(axis=1)
+        e_ref = rel_err(ho, hq, floor).max(axis=1)
+        # (the blips are where the series acceleration is at its worst conditioned: the reference's own distance from exact
+        #  arithmetic there is 1e-9 ... 1e-5)
+        assert (e_dev <= np.maximum(1e-8, 30.0 * e_ref)).all(), (name, float((e_dev / np.maximum(1e-8, 30.0 * e_ref)).max()), sp[np.argmax(e_dev)].tolist())
+    # a block of radii on its own (another chunking of the same columns): same bits
+    c0 = nr // 3
+    hb, db = plan.drawdown_grid(tD, sv, rD[c0:c0 + 7], zD, zl)
+    assert np.array_equal(hb, hg[:, c0:c0 + 7]) and np.array_equal(db, dhg[:, c0:c0 + 7])
+    # oracle on a strided subsample (48 points across the sweep)
+    idx = np.arange(0, nt * nr, (nt * nr) // 48 + 1)
+    it, ir = idx // nr, idx % nr
+    ho, dho = oracle.batch(P, tD[it], rD[ir], sv[it], zD, zl)
+    # (against the reference's own distance from exact arithmetic on those points: the sweeps reach far-field corners where
+    #  that is 1e-8)
+    hq, dhq = oracle_quad.batch(P, tD[it], rD[ir], sv[it], zD, zl, threads=8)
+    e_h, r_h = rel_err(hg[it, ir], hq, floor), rel_err(ho, hq, floor)
+    e_d, r_d = rel_err(dhg[it, ir], dhq, floor), rel_err(dho, dhq, floor)
+    assert e_h.max() <= max(2e-9, 20.0 * r_h.max()), (float(e_h.max()), float(r_h.max()))
+    assert e_d.max() <= max(2e-6, 20.0 * r_d.max()), (float(e_d.max()), float(r_d.max()))
+    assert np.median(e_h) <= max(1e-11, 20.0 * np.median(r_h)) and np.median(e_d) <= max(1e-9, 20.0 * np.median(r_d))
+    # the faithful flavour on a sub-grid of the same sweep (64 times x 6 radii: lane = time as well)
+    pf = engine.Plan(P, mode="faithful")
+    ts_, rs_ = np.arange(0, nt, nt // 64)[:64], np.arange(0, nr, nr // 6)[:6]
+    hf, df = pf.drawdown_grid(tD[ts_], sv[ts_], rD[rs_], zD, zl)
+    assert np.median(rel_err(hg[np.ix_(ts_, rs_)], hf, floor)) < 1e-11 and rel_err(hg[np.ix_(ts_, rs_)], hf, floor).max() < 1e-6
+    assert np.median(rel_err(dhg[np.ix_(ts_, rs_)], df, floor)) < 1e-9 and rel_err(dhg[np.ix_(ts_, rs_)], df, floor).max() < 1e-4
 
 
 def test_edge_cases(engine, oracle, oracle_quad):

@@ -534,6 +534,9 @@ UCF_DEV cplx sample_z(const ucf_dev_params& P, const sample_common& S, int iz)
         } else {
             const cplx g2 = cdiv(cadd(cmul(S.ff1, chz), cmul(S.ff2, ccosh_(cscale(S.eta, 1.0 - zD)))), S.she);   // :278-282
             uDp = (lay == 2) ? rsub(1.0, g2) : csub(ccosh_(cscale(S.eta, P.dD1 - zD)), g2);    // :296 / :290
+#if UCF_FAST
+            if (S.clean3 && lay == 3) uDp = lay3_pick(uDp, lay3_udp_scaled(P, S.eta, zD));       // (resumed items: see lay3_udp_scaled)
+#endif
         }
         return cmul(S.hs_pre, uDp);                                                             // :299
     }
@@ -1336,6 +1339,29 @@ point_kernel(const ucf_dev_params P0, int npts, int per_point, int nr, int nsv, 
 }
 
 #if UCF_FAST
+// ------------------------------------------------------------------ lapTime(p) x the evaluators' constants, once per (time, p)
+// The pumping-schedule multiplier (time.f90:34-122) depends on the time and the Laplace index only -- not on the radius, not
+// on the abscissa: one small launch forms it for every (row, m) of the call, row = index into the call's tD array (the time
+// of a grid, the point of a list), times everything the fast evaluators leave out of their samples (fast_scale; model 2:
+// A0(p) / (p tDb + 1), laplace_hankel_solutions.f90:267-268).  integrate_kernel loads the value instead of carrying the
+// code of eight schedule types, their complex exponentials and the Amos K0 / K1 through its set-up: ltab[m][nrows].
+template <int FAMILY, bool MULTI>
+__global__ void __launch_bounds__(256)
+laptime_kernel(const ucf_dev_params P0, int nrows, const double* __restrict__ tDv, double2* __restrict__ ltab,
+               const ucf_dev_params* __restrict__ Pv, int ppp, int pbase)
+{
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long long)nrows * P0.np) return;
+    const int m = (int)(gid / nrows), row = (int)(gid % nrows);
+    const ucf_dev_params& P = item_params<MULTI>(P0, Pv, row + pbase, ppp);
+    const double tee = 2.0 * tDv[row];                                                          // driver.f90:106,217
+    const double sigma = P.alpha - P.logtol / (2.0 * tee);                                      // invlap.f90:165
+    const cplx p = cmake(sigma, UCF_PI * m / tee);                                              // invlap.f90:168
+    cplx lt = cscale(lap_time(P, p), fast_scale<FAMILY>(P));
+    if (FAMILY == 5) lt = cmul(lt, cdiv(hstorage_A0(P, p), caddr(cscale(p, P.hs_tDb), 1.0)));
+    ltab[gid] = make_double2(lt.re, lt.im);
+}
+
 // ------------------------------------------------------------------ the integration kernel (fast flavour)
 // The abscissa loop of point_kernel on its own (driver.f90:129-157,187-203 with the fast evaluators of
 // ucf_fastpath.h): same work items, same lanes, same accumulation order.  It owns nothing but the loop, so
@@ -1353,7 +1379,7 @@ point_kernel(const ucf_dev_params P0, int npts, int per_point, int nr, int nsv, 
 #endif
 // constants of sincos_tab_ / exp_tab_ kept in VGPRs (sc_ctx::kv)
 #ifndef UCF_KV
-#define UCF_KV(FAMILY, FOLD) ((FAMILY) == 4 ? 0 : (FOLD) ? 1 : 4)
+#define UCF_KV(FAMILY, FOLD) ((FAMILY) == 4 ? 0 : 4)
 #endif
 // WAVES per SIMD the register budget is cut for: as many as the LDS footprint admits (6 for nz = 1 at R = 4,
 // fully penetrating; 5; else 4)
@@ -1364,7 +1390,8 @@ __global__ void __launch_bounds__(UCF_WAVE * UCF_IWPB, WAVES)
 integrate_kernel(const ucf_dev_params P0, int npts, int per_point, int nr, int nsv, int svmin,
                  const double* __restrict__ tDv, const double* __restrict__ rDv, const int* __restrict__ svv,
                  const double2* __restrict__ tab, int nt, int ir0, double2* __restrict__ state, int* __restrict__ ndone,
-                 int* __restrict__ todo, const ucf_dev_params* __restrict__ Pv, int ppp, int pbase)
+                 int* __restrict__ todo, const ucf_dev_params* __restrict__ Pv, int ppp, int pbase, int lsplit,
+                 const double2* __restrict__ ltab, int nrows)
 {
     extern __shared__ lds_c lds[];
 #ifdef UCF_K1_ASSUME
@@ -1374,6 +1401,7 @@ integrate_kernel(const ucf_dev_params P0, int npts, int per_point, int nr, int n
     // (the wave's index within the workgroup is wave-uniform, but only readfirstlane tells the compiler: without it the
     //  work item, its abscissa row and the row's entries live in VGPRs and are fetched by vector loads)
     const int lane = threadIdx.x & (UCF_WAVE - 1), wv = __builtin_amdgcn_readfirstlane(threadIdx.x / UCF_WAVE);
+    constexpr int EF = (FAMILY == 5) ? 1 : FAMILY;      // the evaluator: model 2 runs family 1's with its own lane constant
     const int nz = NZC ? NZC : P0.nz, R = P0.R, nacc = P0.nacc, N = P0.N, ngl = P0.ngl;
     __builtin_assume(nz >= 1 && R >= 1 && nacc >= 1 && ngl >= 1);     // (the launcher's business: no loop guards in the kernel)
     const int nabs = N + nacc * ngl;
@@ -1387,7 +1415,25 @@ integrate_kernel(const ucf_dev_params P0, int npts, int per_point, int nr, int n
     lds_c* const wlds = lds + UCF_SC_ENTRIES + (size_t)wv * (R + 1) * nz * UCF_WAVE;
     lds_c* accTS = wlds;                                    // [R][nz]  level sums
     lds_c* accCur = wlds + (size_t)R * nz * UCF_WAVE;       // [nz]     area of the J0 interval being integrated
-    for (int pt = blockIdx.x * UCF_IWPB + wv; pt < npts; pt += gridDim.x * UCF_IWPB) {
+    // A work item may be cut into 2^lsplit parts of whole quadrature units (the tanh-sinh part, then the J0 intervals: every
+    // level sum and every interval area is formed by ONE part, in the reference's order -- same bits whatever the cut):
+    // small launches (a shard of a strong-scaling run) then still fill the chip and end with a short tail.
+    const int nsplit = 1 << lsplit;
+    for (int wi = blockIdx.x * UCF_IWPB + wv; wi < npts * nsplit; wi += gridDim.x * UCF_IWPB) {
+        const int pt = wi >> lsplit, sub = wi & (nsplit - 1);
+        // abscissae [n0, n1) of part `sub`: boundaries at N + j ngl, j the nearest to an even cut of the nabs abscissae
+        auto part_bound = [&](int k) {
+            if (k <= 0) return 0;
+            if (k >= nsplit) return nabs;
+            int j = (k * nabs / nsplit - N + ngl / 2) / ngl;
+            j = j < 0 ? 0 : (j > nacc ? nacc : j);
+            return N + j * ngl;
+        };
+        const int n0 = part_bound(sub), n1 = part_bound(sub + 1);
+        if (n1 <= n0 && sub != 0) continue;
+#ifdef UCF_TIMELINE      /* diagnostic build (tools/timeline.py): when and where every work item ran */
+        const unsigned long long tl_t0 = __builtin_amdgcn_s_memtime();
+#endif
         const work_item W = decode_item<LAYOUT>(P0, pt, lane, per_point, nr, nt, ir0, npts);
         const ucf_dev_params& P = item_params<MULTI>(P0, Pv, (LAYOUT == 3 ? W.plan * ppp : W.pidx) + pbase, ppp);
         bool need_lay1 = false, need_lay3 = false, need_lay12 = false;
@@ -1400,7 +1446,9 @@ integrate_kernel(const ucf_dev_params P0, int npts, int per_point, int nr, int n
         const cplx p = cmake(sigma, UCF_PI * W.mlap / tee);                                     // invlap.f90:168
         // (the pumping-schedule multiplier lapTime(p) is constant over the abscissae: the sums are formed without it and
         //  scaled when they leave the kernel -- one complex product per sample less)
-        const cplx lt = cscale(lap_time(P, p), fast_scale<FAMILY>(P));      // and the constants the evaluators leave out
+        // times the constants the evaluators leave out: laptime_kernel formed it for every (row of tD, m)
+        const double2 ltv = ltab[(size_t)W.mlap * nrows + W.it];
+        const cplx lt = cmake(ltv.x, ltv.y);
         const lane_consts LC = make_lane_consts(P, p, lt);
         double2* __restrict__ sti = state + (size_t)pt * state_slots(P0) * UCF_WAVE;
         double2* __restrict__ areas = sti + (size_t)(R + 1) * nz * UCF_WAVE;
@@ -1410,28 +1458,28 @@ integrate_kernel(const ucf_dev_params P0, int npts, int per_point, int nr, int n
         // the closure's unscaled reciprocal (fast_common_terms) wants |xi| = |eta| |xifac| far from overflow: an item with a
         // lane beyond that goes to point_kernel whole
         const bool lane_ok = FAMILY != 2 || (fabs(LC.xifac.re) + fabs(LC.xifac.im) < 1.0e90);
-        const int nlim = (__builtin_amdgcn_ballot_w64(!lane_ok) == 0) ? nabs : 0;
+        const int nlim = (__builtin_amdgcn_ballot_w64(!lane_ok) == 0) ? n1 : n0;
 
         // abscissae increase monotonically (tanh-sinh on [0,arg], then the J0 intervals), so does Re(eta):
         // the fast evaluation is valid for a leading run of abscissae; point_kernel finishes the rest.
         // The row entry of the next abscissa is requested one iteration ahead (scalar loads).
-        int n = 0;
-        double2 aa = row[0];
-        int m = 0, jj = 0;                        // Gauss-Lobatto node and J0 interval of abscissa n >= N
+        int n = n0;
+        double2 aa = row[n0 < nabs ? n0 : 0];
+        int m = 0, jj = n0 > N ? (n0 - N) / ngl : 0;   // Gauss-Lobatto node and J0 interval of abscissa n >= N
         cplx acc0 = cmake(0.0, 0.0);              // running area of the interval: a register when nz = 1,
         for (; n < nlim; n++) {                   // else accCur[z] in LDS
             const double2 nxt = row[n + 1 < nabs ? n + 1 : n];
             const bool ts = n < N;
             F.sc.salt = n;
-            if (__builtin_amdgcn_ballot_w64(!fast_eta<FAMILY>(P, LC, aa.x, F)) != 0) break;      // (every lane is live here)
-            fast_common_terms<FAMILY, FOLD, LAY3>(P, LC, aa.x, need_lay1, F, need_lay3, need_lay12);
+            if (__builtin_amdgcn_ballot_w64(!fast_eta<EF>(P, LC, aa.x, F)) != 0) break;          // (every lane is live here)
+            fast_common_terms<EF, FOLD, LAY3>(P, LC, aa.x, need_lay1, F, need_lay3, need_lay12);
             const int n1 = n + 1;
             int tz = __builtin_ctz(n1);
             if (tz > R - 1) tz = R - 1;
             for (int z = 0; z < nz; z++) {
                 // val = a*J0(a rD) * f(a,p,z) [* lapTime(p): at the end]                         (lhs.f90:118)
                 // (Gauss-Lobatto part: aa.y carries the node's weight, abscissa_kernel)
-                const cplx fz = fast_sample_z<FAMILY, FOLD, LAY3>(P, F, z);
+                const cplx fz = fast_sample_z<EF, FOLD, LAY3>(P, F, z);
                 if (ts) {
                     const cplx val = rscale(aa.y, fz);
                     // tanh-sinh on [0, arg]: abscissa n+1 belongs to level j when 2^(R-j) divides it  (driver.f90:129-157)
@@ -1464,16 +1512,29 @@ integrate_kernel(const ucf_dev_params P0, int npts, int per_point, int nr, int n
             }
             aa = nxt;
         }
-        if (nz == 1) lds_st(accCur, 0, lane, acc0);       // an unfinished interval travels with the state
-        // (the running area only matters to point_kernel, i.e. when the item is unfinished)
-        const int nslots = (n < nabs) ? (R + 1) * nz : R * nz;
-        for (int s = 0; s < nslots; s++) {
-            const cplx v = cmul(lds_ld(wlds, s, lane), lt);
-            sti[(size_t)s * UCF_WAVE + lane] = make_double2(v.re, v.im);
+        // What leaves the kernel: the level sums (the part that owns the tanh-sinh abscissae) and the finished areas (above).
+        // A part that had to stop hands over at the START of the J0 interval it was in (inside the tanh-sinh part: at the
+        // abscissa itself, the level sums are additive): point_kernel redoes that interval whole, so that no running area
+        // travels and the parts of an item need not agree on one.  ndone[pt] was set to nabs by the launcher; the smallest
+        // hand-over point of the item's parts counts, the part that lowers it first lists the item.
+        if (sub == 0) {
+            for (int z = 0; z < nz; z++) lds_st(accCur, z, lane, cmake(0.0, 0.0));
+            for (int s = 0; s < (R + 1) * nz; s++) {
+                const cplx v = cmul(lds_ld(wlds, s, lane), lt);
+                sti[(size_t)s * UCF_WAVE + lane] = make_double2(v.re, v.im);
+            }
         }
-        if (lane == 0) {
-            ndone[pt] = n;
-            if (n < nabs) todo[1 + atomicAdd(&todo[0], 1)] = pt;      // point_kernel takes it from here
+#ifdef UCF_TIMELINE      /* into the (unread) running-area slot: lane 0 = (start, end) in shader clocks, lane 1 = (HW_ID, part) */
+        if (sub == 0) {
+            const unsigned long long tl_t1 = __builtin_amdgcn_s_memtime();
+            const unsigned hwid = __builtin_amdgcn_s_getreg(63492);      // HW_REG_HW_ID: wave, SIMD, CU, SH, SE ...
+            if (lane == 0) sti[(size_t)(R * nz) * UCF_WAVE + 0] = make_double2(__longlong_as_double((long long)tl_t0), __longlong_as_double((long long)tl_t1));
+            if (lane == 1) sti[(size_t)(R * nz) * UCF_WAVE + 1] = make_double2((double)hwid, (double)__builtin_amdgcn_s_getreg(63508));   // XCC_ID (reg 20)
+        }
+#endif
+        if (n < n1 && lane == 0) {
+            const int nrep = (n < N) ? n : n - m;
+            if (atomicMin(&ndone[pt], nrep) == nabs) todo[1 + atomicAdd(&todo[0], 1)] = pt;      // point_kernel takes it from here
         }
     }
 }
@@ -1750,10 +1811,13 @@ samples_kernel(const ucf_dev_params P, int n_a, const double* __restrict__ av, d
         sc_ctx_init(F.sc, lds, 0);
         F.sc.salt = ia;
     }
-    if (FAMILY == 1 || FAMILY == 2 || FAMILY == 4) {
+    constexpr int EF = (FAMILY == 5) ? 1 : FAMILY;
+    cplx c5 = cmake(1.0, 0.0);
+    {
         const lane_consts LC = make_lane_consts(P, p, lt);
         const bool lane_ok = FAMILY != 2 || (fabs(LC.xifac.re) + fabs(LC.xifac.im) < 1.0e90);      // as integrate_kernel
-        fast = __all(lane_ok && fast_prepare<FAMILY>(P, LC, a, need_lay1, F));
+        fast = __all(lane_ok && fast_prepare<EF>(P, LC, a, need_lay1, F));
+        if (FAMILY == 5) c5 = cdiv(hstorage_A0(P, p), caddr(cscale(p, P.hs_tDb), 1.0));
     }
 #endif
     const cplx lane_aux = (FAMILY == 5) ? hstorage_A0(P, p) : cmake(0.0, 0.0);
@@ -1761,8 +1825,7 @@ samples_kernel(const ucf_dev_params P, int n_a, const double* __restrict__ av, d
     for (int z = 0; z < P.nz; z++) {
         cplx f;
 #if UCF_FAST
-        if (fast) f = cscale(fast_sample_z<(FAMILY == 1 || FAMILY == 2 || FAMILY == 4) ? FAMILY : 1>(P, F, z),
-                             fast_scale<(FAMILY == 1 || FAMILY == 2 || FAMILY == 4) ? FAMILY : 1>(P));
+        if (fast) f = cmul(cscale(fast_sample_z<EF>(P, F, z), fast_scale<FAMILY>(P)), c5);
         else
 #endif
             f = sample_z<FAMILY>(P, S, z);
@@ -1998,7 +2061,7 @@ static inline int split_kind(const ucf_dev_params& dp)
 {
     const int fam = family_of(dp);
 #if UCF_FAST
-    if (fam == 1 || fam == 2 || fam == 4) return 1;
+    if (fam >= 0 && fam <= 5) return 1;
 #else
     if (fam == 4 && 2 * (size_t)dp.order * UCF_WAVE * sizeof(lds_c) > 16 * 1024) return 0;
 #endif
@@ -2010,6 +2073,13 @@ size_t state_bytes_per_item(const ucf_dev_params& dp)
 {
     return split_kind(dp) ? (size_t)(dp.R + 1 + dp.nacc) * dp.nz * UCF_WAVE * sizeof(lds_c) : 0;
 }
+#if UCF_FAST
+// bytes of the lapTime table of a launch over `rows` rows of tD (behind the state in the same buffer; laptime_kernel)
+size_t lt_table_bytes(const ucf_dev_params& dp, size_t rows)
+{
+    return split_kind(dp) == 1 ? rows * dp.np * sizeof(lds_c) : 0;
+}
+#endif
 #endif
 
 // The transform stage for `nwork` work items of lane layout LAYOUT: [integrate kernel -> finish_kernel ->] point_kernel.
@@ -2040,10 +2110,39 @@ static int launch_transform_(const ucf_dev_params& dp, int nwork, int per_point,
     }
 #if UCF_FAST
     if (kind == 1) {
+        // every item starts as "all abscissae done"; the parts that must stop lower it (integrate_kernel)
+        (void)hipMemsetD32Async((hipDeviceptr_t)d_ndone, dp.N + dp.nacc * dp.ngl, (size_t)nwork, s);
+        // parts per item: launches of fewer than ~8 rounds of resident waves (256 CUs x 4 SIMDs x <= 6 waves) run two parts
+        // per item -- measured on the 1/8 shard of C2 (27 136 items, tools/gpu_shard.sh): 5.37 / 5.26 / 5.35 / 5.58 ms with
+        // 1 / 2 / 4 / 8 parts (every part pays the item's set-up again).  UCF_NSPLIT (diagnostic): force 1, 2, 4 or 8 parts.
+        static const int force_split = [] { const char* e = std::getenv("UCF_NSPLIT"); return e ? std::atoi(e) : 0; }();
+        int lsplit = 0;
+        while (lsplit < 1 && ((long long)nwork << lsplit) < 8LL * 256 * 4 * 6) lsplit++;
+        if (force_split > 0) { lsplit = 0; while ((1 << (lsplit + 1)) <= force_split && lsplit < 3) lsplit++; }
+        if ((1 << lsplit) > dp.nacc + 1) lsplit = 0;
         // per workgroup: the sin/cos table + UCF_IWPB waves' accumulators; wlds = the footprint one wave accounts for
         const size_t wlds = (size_t)(dp.R + 1) * dp.nz * UCF_WAVE * sizeof(lds_c) + UCF_SC_ENTRIES * sizeof(lds_c) / UCF_IWPB;
         const size_t ilds = wlds * UCF_IWPB;
-        const dim3 igrid((unsigned)((nwork + UCF_IWPB - 1) / UCF_IWPB)), iblock(UCF_WAVE * UCF_IWPB);
+        const dim3 igrid((unsigned)((((long long)nwork << lsplit) + UCF_IWPB - 1) / UCF_IWPB)), iblock(UCF_WAVE * UCF_IWPB);
+        // lapTime(p) x constants for every (row of the call's tD, m): rows = the times of a grid / the points of a list.
+        // The table lives behind the state of this launch's work items (the caller sized the buffer for it: lt_table_bytes)
+        const int nrows = (LAYOUT == 1) ? nt : (LAYOUT == 3 ? nt : (LAYOUT == 2 ? nwork / ((dp.np + UCF_WAVE - 1) / UCF_WAVE) : nwork));
+        double* const d_ltab = d_state + (size_t)nwork * (dp.R + 1 + dp.nacc) * dp.nz * UCF_WAVE * 2;
+        {
+            const long long nlt = (long long)nrows * dp.np;
+            const dim3 lgrid((unsigned)((nlt + 255) / 256)), lblock(256);
+#define UCF_LAUNCH_LT(F) hipLaunchKernelGGL((laptime_kernel<F, MULTI>), lgrid, lblock, 0, s, dp, nrows, d_tD, (double2*)d_ltab, d_params, ppp, pbase)
+            ucf_tm_mark(tm, UCF_STR(UCF_NS) "::laptime_kernel", s);
+            switch (fam) {
+            case 0: UCF_LAUNCH_LT(0); break;
+            case 1: UCF_LAUNCH_LT(1); break;
+            case 2: UCF_LAUNCH_LT(2); break;
+            case 3: UCF_LAUNCH_LT(3); break;
+            case 4: UCF_LAUNCH_LT(4); break;
+            case 5: UCF_LAUNCH_LT(5); break;
+            }
+#undef UCF_LAUNCH_LT
+        }
 #define UCF_LAUNCH_I4(F, W, FO, L3, NZC)                                                                       \
     do {                                                                                                       \
         if (ilds > 64 * 1024)                                                                                  \
@@ -2051,14 +2150,19 @@ static int launch_transform_(const ucf_dev_params& dp, int nwork, int per_point,
         std::snprintf(kname, sizeof(kname), UCF_STR(UCF_NS) "::integrate_kernel<%d, %d, %d, %s, %s, %s, %d>", F, LAYOUT, W, MULTI ? "true" : "false", FO ? "true" : "false", L3 ? "true" : "false", NZC); \
         ucf_tm_mark(tm, kname, s);                                                                             \
         hipLaunchKernelGGL((integrate_kernel<F, LAYOUT, W, MULTI, FO, L3, NZC>), igrid, iblock, ilds, s, dp, nwork, per_point, nr, nsv, svmin, \
-                           d_tD, d_rD, d_sv, (const double2*)d_tab, nt, ir0, (double2*)d_state, d_ndone, d_todo, d_params, ppp, pbase); \
+                           d_tD, d_rD, d_sv, (const double2*)d_tab, nt, ir0, (double2*)d_state, d_ndone, d_todo, d_params, ppp, pbase, lsplit, \
+                           (const double2*)d_ltab, nrows);                                                     \
     } while (0)
+    // launches of ONE depth of the fully penetrating water-table family in the lane = time layout (the headline sweep) run
+    // an instantiation that knows nz = 1 at compile time: no depth loop, no running area in LDS (measured on C2: -2.4 %).
+    // Only there: the unfolded and the finite-difference kernels LOSE 12 ... 46 % to it (C2pp 88 -> 100 ms, C4 237 -> 266,
+    // C5 204 -> 297: the compiler hoists the depth's constants into registers those kernels do not have)
 #ifndef UCF_NZC
-#define UCF_NZC 0              /* 1: launches of one depth run the instantiation that knows nz = 1 at compile time */
+#define UCF_NZC(F, FO) (LAYOUT == 1 && (F) == 2 && (FO) ? 1 : 0)
 #endif
 #define UCF_LAUNCH_I3(F, W, FO, L3)                                                                            \
     do {                                                                                                       \
-        if (UCF_NZC && dp.nz == 1) UCF_LAUNCH_I4(F, W, FO, L3, (UCF_NZC ? 1 : 0));                             \
+        if (UCF_NZC(F, FO) && dp.nz == 1) UCF_LAUNCH_I4(F, W, FO, L3, UCF_NZC(F, FO));                         \
         else UCF_LAUNCH_I4(F, W, FO, L3, 0);                                                                   \
     } while (0)
         // a depth above the screen top anywhere in the call (in any plan of a parameter batch)?
@@ -2072,7 +2176,12 @@ static int launch_transform_(const ucf_dev_params& dp, int nwork, int per_point,
         const bool w5 = wlds * 20 <= 160 * 1024;
         // fully penetrating pumping well (every plan of a parameter batch must be): the screen terms are compiled out
         const bool fold = dp.fold_dD && dp.fold_lD1 && !MULTI;
+        // (parameter batches: the water-table and Hantush families only, ucf_drawdown_multi)
+        if (MULTI && (fam == 0 || fam == 3 || fam == 5)) return UCF_ERR_UNSUPPORTED;
         switch (fam) {
+        case 0: if constexpr (!MULTI) { if (wlds * 24 <= 160 * 1024) UCF_LAUNCH_FOLD(0, 6); else UCF_LAUNCH_FOLD(0, 4); } break;
+        case 3: if constexpr (!MULTI) UCF_LAUNCH_FOLD(3, 4); break;       // (MNtype 1 is fully penetrating by construction, driver_io.f90:159-186)
+        case 5: if constexpr (!MULTI) { if (fold) UCF_LAUNCH_FOLD(5, 4); else UCF_LAUNCH_UNF(5, 4); } break;
         case 1: if (fold) UCF_LAUNCH_FOLD(1, 4); else UCF_LAUNCH_UNF(1, 4); break;
         case 2:
             if (fold) {
@@ -2113,10 +2222,10 @@ static int launch_transform_(const ucf_dev_params& dp, int nwork, int per_point,
                            d_tD, d_rD, d_sv, (const double2*)d_tab, nt, ir0, (double2*)d_state, d_ndone);      \
     } while (0)
         switch (fam) {
+#if !UCF_FAST                   /* the fast flavour has integrate_kernel for every family */
         case 0: UCF_LAUNCH_G(0); break;
         case 3: UCF_LAUNCH_G(3); break;
         case 5: UCF_LAUNCH_G(5); break;
-#if !UCF_FAST                   /* the fast flavour has integrate_kernel for these */
         case 1: UCF_LAUNCH_G(1); break;
         case 2: UCF_LAUNCH_G(2); break;
         case 4: UCF_LAUNCH_G(4); break;

@@ -1,5 +1,6 @@
-// ucf_fastpath.h -- "fast" flavour of the Hantush-based sample evaluators (families 1, 2, 4:
-// Hantush, Moench / Malama / Neuman water-table closure, Mishra-Neuman FD).
+// ucf_fastpath.h -- "fast" flavour of the sample evaluators: families 1, 2, 4 (Hantush, Moench / Malama / Neuman
+// water-table closure, Mishra-Neuman FD), 0 (Theis: the reciprocal alone), 5 (Hantush with wellbore storage: family 1
+// times a per-lane constant) and 3 (Mishra-Neuman in Malama's closed form).
 //
 // Same formulas as laplace_hankel_solutions.f90:64-93,133-202 (cited per line below), evaluated
 // with the minimum of work a wave needs:
@@ -118,6 +119,7 @@ UCF_DEV cplx cinv_auto(cplx z)
 struct lane_consts {     // per lane, constant over the abscissa loop of one point
     cplx p, lt, xifac;   // xifac = alphaD/p [* MoenchM / sum_m 1/(1+p/gamma_m)]   (:70,72-75)
     cplx fdB1;           // FD: p*beta0*exp(-beta2)/kappa                          (:492)
+    cplx mnpv;           // MN-Malama: 1 + p vartheta / (kappa u0^2): (eta1/u0)^2 + 1 without its a^2 term   (:428-432)
 };
 
 UCF_DEV lane_consts make_lane_consts(const ucf_dev_params& P, cplx p, cplx lt)
@@ -133,6 +135,7 @@ UCF_DEV lane_consts make_lane_consts(const ucf_dev_params& P, cplx p, cplx lt)
     }
     L.xifac = xf;
     L.fdB1 = cscale(cscale(cscale(p, P.fd_beta0), P.fd_expmb2), P.inv_kappa);
+    L.mnpv = radd(1.0, cscale(p, P.mn_vartheta * P.mn_c3));
     return L;
 }
 
@@ -141,6 +144,10 @@ struct fast_common {
     cplx th, eta, ff1, ff2, inv_she, she, che, top, g3, inv_den, ex1;   // ex1 = exp(-eta)
     fprim p1;            // primitive of eta itself (valid when have_p1)
     int have_p1;         // (wave-uniform flags are ints: a uniform bool that crosses a join is rebuilt through VALU selects)
+    cplx mn_uod;         // MN-Malama: u / Delta_0                                                     (:437-439)
+#ifdef UCF_SINGLE_RCP    /* investigation build only (tools/dbg_single_rcp.py): NOT the product */
+    cplx q, den;
+#endif
     cplx fd_s1;          // FD: sigma(1)
     cplx top3, fd_s13;   // the same two for depths above the screen top (cancellation-free water-table value)
     bool small_eta, fd_use, fd_use3;
@@ -154,6 +161,10 @@ struct fast_common {
 template <int FAMILY>
 UCF_DEV double fast_scale(const ucf_dev_params& P)
 {
+    // (family 0 and 3: theis and 2 / (kappa eta^2) = 2 / q; family 5: uDf / bD carries no 2, its A0 / (p tDb + 1) is the
+    //  caller's lane constant)
+    if (FAMILY == 0 || FAMILY == 3) return 2.0;
+    if (FAMILY == 5) return P.inv_bD;
     return (FAMILY == 2 && P.model == 4) ? 2.0 : 2.0 * P.inv_bD;
 }
 
@@ -165,10 +176,14 @@ UCF_DEV bool fast_eta(const ucf_dev_params& P, const lane_consts& L, double a, f
 {
     const double a2 = a * a;
     const cplx q = caddr(L.p, a2);
+#ifdef UCF_SINGLE_RCP
+    S.q = q;
+#endif
     {
         const double r = fast_rcp(q.re * q.re + q.im * q.im);
         S.th = cmake(q.re * r, -(q.im * r));                      // HALF of theis = 2/q (:122-131): see fast_scale()
     }
+    if (FAMILY == 0) return q.re > 0.0;                           // Theis is that reciprocal and nothing else
     {   // eta = sqrt(q/kappa), Re q > 0                                                         (:69,172)
         const double qr = q.re * P.inv_kappa, qi = q.im * P.inv_kappa;
         double r, hr;
@@ -189,6 +204,21 @@ UCF_DEV void fast_common_terms(const ucf_dev_params& P, const lane_consts& L, do
                                bool need_lay3_in = false, bool need_lay12 = true)
 {
     const double a2 = a * a;
+    if (FAMILY == 0) return;
+    if (FAMILY == 3) {
+        // Mishra-Neuman, Malama's closed form (:404-442): v = sqrt(1 + (eta1 / u0)^2), eta1^2 = (p vartheta + a^2) / kappa;
+        // u = u0 (1 - v); Delta0 = eta sinh(eta) - u cosh(eta); the sample is (2 / q) (1 + (u / Delta0) cosh(eta zD))
+        const fprim p1 = prim<true>(S.eta.re, S.eta.im, S.sc);
+        S.che = pcosh(p1);
+        S.she = psinh(p1);
+        const double wr = __builtin_fma(a2, P.mn_c3, L.mnpv.re), wi = L.mnpv.im;          // 1 + (eta1 / u0)^2, Re > 0
+        double vr, hr;
+        sqrt_hrsqrt(0.5 * (sqrt_only(__builtin_fma(wr, wr, wi * wi)) + wr), &vr, &hr);
+        const cplx u = cmake(P.mn_u0 * (1.0 - vr), -(P.mn_u0 * (wi * hr)));
+        const cplx Delta0 = cfnma(u, S.che, cmul(S.eta, S.she));
+        S.mn_uod = cmul(u, cinv_auto(Delta0));
+        return;
+    }
     const bool hantush = !(FAMILY == 2 && P.model == 4);
     const bool z1 = FOLD || P.fold_dD != 0, z2 = FOLD || P.fold_lD1 != 0;
     const bool need_lay1 = FOLD ? false : need_lay1_in;           // a fully penetrating screen has no layer below it
@@ -272,6 +302,21 @@ UCF_DEV void fast_common_terms(const ucf_dev_params& P, const lane_consts& L, do
             if (S.small_eta) S.inv_den = cinv_plain(cfma(xi, S.she, S.che));
             else S.inv_den = cinv_plain(radd(1.0, xi));
         }
+#ifdef UCF_SINGLE_RCP
+        // the rejected form: where the Hantush factor and the water-table value are both 1/q the sample
+        // (1/q)(1 - f_z / den) is taken as (den - f_z) / (q den) -- one reciprocal, no 1/q of its own
+        if (FOLD || !hantush) {
+            cplx den;
+            if (P.beta != 0.0) {
+                const cplx one_bex = radd(1.0, cmul(rscale(P.beta, S.eta), xi));
+                den = S.small_eta ? cfma(one_bex, S.che, cmul(xi, S.she)) : cadd(one_bex, xi);
+            } else {
+                den = S.small_eta ? cfma(xi, S.she, S.che) : radd(1.0, xi);
+            }
+            S.den = den;
+            S.inv_den = cinv_auto(cmul(S.q, den));
+        }
+#endif
     }
     if (FAMILY == 4) {
         // Mishra/Neuman finite-difference vadose zone (:444-544): sigma(1) of the tridiagonal system by
@@ -372,6 +417,11 @@ UCF_DEV cplx fast_sample_z(const ucf_dev_params& P, const fast_common& S, int iz
     const double zD = P.zD[iz];
     const int lay = P.zLay[iz];
     cplx chz, exz = cmake(0.0, 0.0);
+    if (FAMILY == 0) return S.th;                                                                // :122-131
+    if (FAMILY == 3) {
+        const cplx cz = pcosh(prim<true>(S.eta.re * zD, S.eta.im * zD, S.sc));
+        return cfma(S.th, cmul(S.mn_uod, cz), S.th);                                            // :437-439 (x fast_scale)
+    }
     if (FAMILY == 1) return fast_hantush_z<1, FOLD, LAY3>(P, S, zD, lay, &chz, &exz);
     if (FAMILY == 4) {
         const cplx sH = fast_hantush_z<4, FOLD, LAY3>(P, S, zD, lay, &chz, &exz);
@@ -387,6 +437,9 @@ UCF_DEV cplx fast_sample_z(const ucf_dev_params& P, const fast_common& S, int iz
         u = fast_hantush_z<2, FOLD, LAY3>(P, S, zD, lay, &chz, &exz);
         if (S.any_large && lay == 1) { const double c = 1.0 - zD; exz = expneg_direct(S.eta.re * c, S.eta.im * c, S.sc); }
     }
+#ifdef UCF_SINGLE_RCP
+    if (FOLD || P.model == 4) return cmul(csub(S.den, S.small_eta ? chz : exz), S.inv_den);
+#endif
     const cplx top = (!FOLD && LAY3 && P.model != 4 && lay == 3) ? S.top3 : S.top;
     // u - top (cosh(eta zD) | exp(eta (zD - 1))) / den  (:85-87 | :89-91); a wave that is on one form only (the usual case)
     // does not select per lane

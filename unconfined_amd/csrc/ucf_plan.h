@@ -32,7 +32,7 @@ struct ucf_dev_params {
     // Hantush with wellbore storage (:204-301): rDw, CDw (:250), tDb (:253)
     double hs_rDw, hs_CDw, hs_tDb;
     // Mishra/Neuman (Malama form, :404-442): host-evaluated scalar prefactors
-    double mn_vartheta, mn_u0;
+    double mn_vartheta, mn_u0, mn_c3;         // mn_c3 = 1 / (kappa u0^2): (eta1 / u0)^2 = (p vartheta + a^2) mn_c3
     // Mishra/Neuman FD (:444-544)
     double fd_h, fd_invhsq, fd_beta0, fd_beta3, fd_expmb2;   // exp(-beta2)
     double fd_isk, fd_gmax;                   // 1/sqrt(K), K = (1/h^2 - beta3/h)/h^2 (0 if K <= 0); 2^(500/order) - 1 (fd_inverse_B2)
@@ -197,6 +197,7 @@ int launch_samples(const ucf_dev_params& dp, int n_a, const double* d_a, double 
                    void* stream);
 // bytes of integrate_kernel -> point_kernel state per work item (0 where the flavour / model has no integrate_kernel)
 size_t state_bytes_per_item(const ucf_dev_params& dp);
+size_t lt_table_bytes(const ucf_dev_params& dp, size_t rows);
 int launch_wynn_regs(int n, int nterms, const double* d_series, double* d_acc, int* d_status, void* stream);
 int launch_dehoog_tiles_hook(const ucf_dev_params& dp, int n, const double* d_tD, const double* d_totlap, double* d_h, double* d_dh, void* stream);
 }
