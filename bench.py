@@ -53,7 +53,7 @@ FLOP_PER_SAMPLE = 1420.0
 FLOP_TAIL_PER_POINT = 0.1e6
 PEAK_FP64_VALU_TFLOPS = 78.6
 PEAK_HBM_GBS = 8000.0
-PROFILE = os.path.join(ROOT, "profiles", "pmc_r02.json")
+PROFILE = os.path.join(ROOT, "profiles", "pmc_r03.json")
 
 
 def c2_deck():
@@ -201,7 +201,7 @@ def self_launch(args):
 
 
 def load_profile(build_id, workload, mode):
-    """per-kernel counters of this workload from profiles/pmc_r02.json -- only if they were taken on THIS build"""
+    """per-kernel counters of this workload from profiles/pmc_r03.json -- only if they were taken on THIS build"""
     try:
         prof = json.load(open(PROFILE))
     except Exception as exc:
@@ -211,7 +211,7 @@ def load_profile(build_id, workload, mode):
         return None, f"profile has no entry for workload {workload} / {mode}"
     if ent.get("build_id") != build_id:
         return None, f"profile was taken on build {ent.get('build_id')}, this library is build {build_id}: refused"
-    return ent, f"profiles/pmc_r02.json (rocprofv3 --pmc, build {build_id}, {ent.get('points_per_launch')} points per launch)"
+    return ent, f"profiles/pmc_r03.json (rocprofv3 --pmc, build {build_id}, {ent.get('points_per_launch')} points per launch)"
 
 
 def worker(args):

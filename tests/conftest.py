@@ -35,7 +35,7 @@ def _parity_report():
         import test_gpu_parity
         if not test_gpu_parity.PARITY:
             return
-        out = os.environ.get("UCF_PARITY_OUT", os.path.join(ROOT, "gpurun_out", "parity_r02.json"))
+        out = os.environ.get("UCF_PARITY_OUT", os.path.join(ROOT, "gpurun_out", "parity_r03.json"))
         os.makedirs(os.path.dirname(out), exist_ok=True)
         from unconfined_amd import engine
         rep = {"build_id": engine.build_id(),

@@ -245,7 +245,7 @@ def test_shard_device_entry_fills_its_rows_in_place(engine):
 def test_parameter_batched_sweep_vs_oracle(engine, oracle, oracle_quad):
     """f4 against the oracle (not only against itself): every plan of a parameter batch, and a plan given new
     parameters by ucf_plan_update, under the end-to-end gate |gpu - ref| <= max(1e-10, 5 x the reference's own
-    distance from the binary128 evaluation on these points) -- 10 x, not the 20 x of the deck gates: profiles/parity_r02.json
+    distance from the binary128 evaluation on these points) -- 10 x, not the 20 x of the deck gates: profiles/parity_r03.json
     showed this one using 6 % (h) / 17 % (dh) of a 20 x bound; a 5 x gate turned out to sit inside the rounding noise of the
     evaluators (a change of the exp primitive from 1 ulp to 1 ulp moved one dh value from 3.4 x to 5.8 x)"""
     from unconfined_amd.abi import params_from_deck

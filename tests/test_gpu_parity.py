@@ -37,7 +37,7 @@ pytestmark = pytest.mark.gpu
 NAMES = deck_names()
 MODES = ["faithful", "fast"]
 # how much of every gate's slack is used: worst err / bound per deck x flavour, written to
-# gpurun_out/parity_r02.json when the session ends (tests/conftest.py) and kept under profiles/
+# gpurun_out/parity_r03.json when the session ends (tests/conftest.py) and kept under profiles/
 PARITY = {}
 
 

@@ -2,15 +2,15 @@
 """Copy the evidence of tools/gpu_final.sh from gpurun_out/ (scratch) into profiles/ (tracked):
   profiles/<tag>_<workload>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary
   profiles/<tag>_bench_<...>.json              bench lines
-  profiles/pmc_r02.json                        per workload and kernel: counters per launch, executed fp64 flop, VALU-busy,
+  profiles/pmc_r03.json                        per workload and kernel: counters per launch, executed fp64 flop, VALU-busy,
                                                HBM bytes -- each entry stamped with the build id of the library that ran
                                                (bench.py only uses entries whose build id is its own library's)
 usage: tools/collect_profiles.py [tag]"""
 import collections, csv, glob, json, os, re, shutil, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 G, P = os.path.join(R, "gpurun_out"), os.path.join(R, "profiles")
-NABS = {"c2": 543, "c2pp": 543, "c3": 543, "c4": 703, "c5": 543}
+WORKLOADS = ("c2", "c2pp", "c3", "c4", "c5", "c1", "hstorage", "mnm")
 
 
 def norm(name):
@@ -46,7 +46,7 @@ def counters(d):
     return {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in out.items()}
 
 
-prof_path = os.path.join(P, "pmc_r02.json")
+prof_path = os.path.join(P, "pmc_r03.json")
 try:
     prof = json.load(open(prof_path))
 except Exception:
@@ -57,7 +57,7 @@ prof["what"] = ("rocprofv3 --pmc passes of tools/gpu_final.sh over `python3 benc
                 "valu_busy = SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs); hbm_bytes_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) KB "
                 "(MI355X_MICROARCH.md: FETCH_SIZE reports half of wide coalesced reads on gfx950; separate passes, the TCC counters do not fit one); "
                 "*_per_wave_abscissa = instructions / SQ_WAVES / abscissae of the workload (integrate kernels only)")
-for W in ("c2", "c2pp", "c3", "c4", "c5"):
+for W in WORKLOADS:
     ks = sorted(glob.glob(os.path.join(G, f"fin_{W}_trace", "*", "*kernel_stats.csv")), key=os.path.getmtime)
     if ks:
         shutil.copy(ks[-1], os.path.join(P, f"{tag}_{W}_kernel_stats.csv"))
@@ -66,6 +66,7 @@ for W in ("c2", "c2pp", "c3", "c4", "c5"):
     fe, wr = counters(f"fin_{W}_FETCH_SIZE"), counters(f"fin_{W}_WRITE_SIZE")
     if not line or not sq:
         continue
+    nabs = int(re.search(r"\((\d+) abscissae", line["config"]["workload"]).group(1))
     kern = {}
     for k in sorted(set(sq) | set(f64) | set(fe) | set(wr)):
         if "ucf_" not in k:
@@ -76,13 +77,13 @@ for W in ("c2", "c2pp", "c3", "c4", "c5"):
             arith = c["SQ_INSTS_VALU_FMA_F64"] + c["SQ_INSTS_VALU_ADD_F64"] + c["SQ_INSTS_VALU_MUL_F64"] + c["SQ_INSTS_VALU_TRANS_F64"]
             e["fp64_flop_per_launch"] = 64.0 * (arith + c["SQ_INSTS_VALU_FMA_F64"])
             if "integrate" in k and c.get("SQ_WAVES"):
-                e["fp64_arith_per_wave_abscissa"] = arith / c["SQ_WAVES"] / NABS[W]
+                e["fp64_arith_per_wave_abscissa"] = arith / c["SQ_WAVES"] / nabs
         # (only for the long kernels: GRBM_GUI_ACTIVE of a 2 ms kernel is dominated by ramp-up and drain and the ratio overshoots 1)
         if c.get("GRBM_GUI_ACTIVE") and "SQ_ACTIVE_INST_VALU" in c and ("integrate" in k or "point_kernel" in k):
             e["valu_busy"] = min(1.0, c["SQ_ACTIVE_INST_VALU"] * 4 / (c["GRBM_GUI_ACTIVE"] / 8 * 1024))
         if "integrate" in k and c.get("SQ_WAVES") and "SQ_INSTS_VALU" in c:
-            e["valu_per_wave_abscissa"] = c["SQ_INSTS_VALU"] / c["SQ_WAVES"] / NABS[W]
-            e["salu_per_wave_abscissa"] = c["SQ_INSTS_SALU"] / c["SQ_WAVES"] / NABS[W]
+            e["valu_per_wave_abscissa"] = c["SQ_INSTS_VALU"] / c["SQ_WAVES"] / nabs
+            e["salu_per_wave_abscissa"] = c["SQ_INSTS_SALU"] / c["SQ_WAVES"] / nabs
         if k in fe or k in wr:
             f_, w_ = fe.get(k, {}).get("FETCH_SIZE", 0.0), wr.get(k, {}).get("WRITE_SIZE", 0.0)
             e["FETCH_SIZE_KB"], e["WRITE_SIZE_KB"] = f_, w_
@@ -100,11 +101,13 @@ try:        # where there is a git checkout (the build container, not the GPU bo
 except Exception:
     pass
 json.dump(prof, open(prof_path, "w"), indent=1, sort_keys=True)
-for n in ("bench_default", "bench_faithful", "bench_c2pp", "bench_c3", "bench_c4", "bench_c5", "bench_gpus2_strong", "bench_gpus2_weak"):
+for n in ("bench_default", "bench_faithful", "bench_c2pp", "bench_c3", "bench_c4", "bench_c5", "bench_c1", "bench_hstorage", "bench_mnm", "bench_gpus2_strong",
+          "bench_gpus2_weak", "bench_nt128"):
     line = bench_line(os.path.join(G, n + ".log"))
     if line:
         json.dump(line, open(os.path.join(P, f"{tag}_{n}.json"), "w"))
         r = line["roofline"]
         print(n, round(line["value"]), "pt/s", "kernel_ms", round(r["kernel_ms"], 2), "x", r.get("kernel_launches_per_step"), "frac", r.get("frac"))
-if os.path.exists(os.path.join(G, "parity_r02.json")):
-    shutil.copy(os.path.join(G, "parity_r02.json"), os.path.join(P, "parity_r02.json"))
+for f in ("parity_r03.json", "stages_r03.json"):
+    if os.path.exists(os.path.join(G, f)):
+        shutil.copy(os.path.join(G, f), os.path.join(P, f))

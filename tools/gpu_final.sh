@@ -19,7 +19,7 @@ run() { # name, rocprof args..., then bench args after --
   timeout -k 10 500 rocprofv3 "$@" > $R/gpurun_out/$name.log 2>&1; local rc=$?
   echo "[$name] rc=$rc"; [ $rc -ge 124 ] && exit $rc; return 0
 }
-for W in ${WORKLOADS:-c2 c2pp c3 c4 c5}; do
+for W in ${WORKLOADS:-c2 c2pp c3 c4 c5 c1 hstorage mnm}; do
   B="python3 $R/bench.py --warmup 1 --no-cpu --workload $W"
   run fin_${W}_trace --kernel-trace --stats --output-format csv -d $R/gpurun_out/fin_${W}_trace -- $B --steps 3
   run fin_${W}_sq --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/fin_${W}_sq -- $B --steps 1
@@ -28,15 +28,17 @@ for W in ${WORKLOADS:-c2 c2pp c3 c4 c5}; do
   run fin_${W}_WRITE_SIZE --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/fin_${W}_WRITE_SIZE -- $B --steps 1
 done
 cd $R
-# the counters of THIS build become profiles/pmc_r02.json on the box, so that the bench lines below carry their roofline
-python3 tools/collect_profiles.py ${TAG:-r02} > gpurun_out/collect.log 2>&1; cp profiles/pmc_r02.json gpurun_out/pmc_r02.json
+# the counters of THIS build become profiles/pmc_r03.json on the box, so that the bench lines below carry their roofline
+python3 tools/collect_profiles.py ${TAG:-r03} > gpurun_out/collect.log 2>&1; cp profiles/pmc_r03.json gpurun_out/pmc_r03.json
 [ -n "$SKIP_TESTS" ] && exit 0
 timeout -k 10 1000 python -m pytest tests -m gpu -q --no-header -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1; rc=$?; echo "[pytest] rc=$rc $(tail -1 gpurun_out/pytest_gpu.log)"; [ $rc -ge 124 ] && exit $rc
 timeout -k 10 600 python bench.py > gpurun_out/bench_default.log 2> gpurun_out/bench_default.err; rc=$?; echo "[bench] rc=$rc"; [ $rc -ge 124 ] && exit $rc
 timeout -k 10 600 python bench.py --mode faithful --no-cpu > gpurun_out/bench_faithful.log 2> gpurun_out/bench_faithful.err; rc=$?; echo "[bench faithful] rc=$rc"
-for W in c2pp c3 c4 c5; do
+for W in c2pp c3 c4 c5 c1 hstorage mnm; do
   timeout -k 10 600 python bench.py --no-cpu --workload $W --steps 3 > gpurun_out/bench_$W.log 2> gpurun_out/bench_$W.err; echo "[bench $W] rc=$?"
 done
+# the per-rank work of a strong-scaling run of C2 at N = 8 (128 of the 1024 time rows) on this one GPU
+timeout -k 10 300 python bench.py --no-cpu --nt 128 --steps 20 --warmup 2 > gpurun_out/bench_nt128.log 2> gpurun_out/bench_nt128.err; echo "[bench nt128] rc=$?"
 # rehearsal of the N > 1 path on this one-GPU box: bench.py starts its own two ranks (both on cuda:0, gloo), strong and weak
 for S in strong weak; do
   UCF_BENCH_ONE_DEVICE=1 UCF_BENCH_BACKEND=gloo timeout -k 10 600 python bench.py --gpus 2 --steps 3 --scaling $S > gpurun_out/bench_gpus2_$S.log 2> gpurun_out/bench_gpus2_$S.err; echo "[bench --gpus 2 $S] rc=$?"

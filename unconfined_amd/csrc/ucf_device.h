@@ -648,11 +648,13 @@ UCF_DEV double dehoog_wave(cplx f, int M, double alpha, double logtol, double t,
 // quotient below where it can).
 // q(i,r+1) = q(i+1,r) e(i+1,r) / e(i,r) (:93).  Fast flavour: product times conj(e)/|e|^2 without the exponent scaling of
 // __divdc3 when every lane's |e| is far from over- and underflow of its square (the lanes outside the rhombus hold 1).
-UCF_DEV cplx qd_quotient(cplx qn, cplx enn, cplx enew)
+// `valid`: this lane's entry belongs to the rhombus (the others carry whatever the shifts brought: they never feed a valid
+// entry -- q(i,r+1) needs e(i+1,r), e(i,r+1) needs q(i+1,r+1), both inside -- and must not decide the wave's path)
+UCF_DEV cplx qd_quotient(cplx qn, cplx enn, cplx enew, bool valid)
 {
 #if UCF_FAST
     const double m = fmax(fabs(enew.re), fabs(enew.im));
-    if (__builtin_amdgcn_ballot_w64(!(m < 1.0e150 && m > 1.0e-150)) == 0) {
+    if (__builtin_amdgcn_ballot_w64(valid && !(m < 1.0e150 && m > 1.0e-150)) == 0) {
         const double r = fast_rcp(__builtin_fma(enew.re, enew.re, enew.im * enew.im));
         const cplx num = cmul(qn, enn);
         return cmake((num.re * enew.re + num.im * enew.im) * r, (num.im * enew.re - num.re * enew.im) * r);
@@ -667,10 +669,17 @@ UCF_DEV void dehoog_qd_wave(cplx f, int M, int lane, ucf_stats* st, bool* zero, 
 {
     const int n2 = 2 * M;
     const bool act = lane <= n2;
-    double mag = act ? cabs_(f) : 0.0;
-    if (d_isnan(mag)) mag = 0.0;                         // MAXVAL skips NaN operands
-    const double mx = wave_max(mag);
-    *zero = !(mx > UCF_DBL_MIN);                         // :69,139
+    // maxval(abs(f)) > tiny (:69,139; MAXVAL skips NaN operands): the larger component decides wherever it is clear of the
+    // threshold by the factor sqrt 2 that hypot can add; only a vector at the very edge of the denormals asks hypot itself
+    double mag = act ? fmax(fabs(f.re), fabs(f.im)) : 0.0;            // (fmax drops a NaN operand; NaN, NaN -> NaN -> 0 below)
+    if (d_isnan(mag)) mag = 0.0;
+    double mx = wave_max(mag);
+    if (__builtin_expect(!(mx > UCF_DBL_MIN) && mx > 0.7 * UCF_DBL_MIN, 0)) {
+        mag = act ? cabs_(f) : 0.0;
+        if (d_isnan(mag)) mag = 0.0;
+        mx = wave_max(mag);
+    }
+    *zero = !(mx > UCF_DBL_MIN);
     if (*zero) {
         if (st) stat_add(&st->zero_vectors, lane == 0);
         return;
@@ -683,20 +692,29 @@ UCF_DEV void dehoog_qd_wave(cplx f, int M, int lane, ucf_stats* st, bool* zero, 
     if (lane == 0) dcol[0] = make_double2(d0.re, d0.im);
     cplx fnext = shfl_down1(ff);
     cplx q = (lane == 0) ? cdiv(fnext, d0) : cdiv(fnext, ff);                                   // :81-82  q(i,1)
-    if (lane > n2 - 1) q = cmake(1.0, 0.0);
     cplx en = cmake(0.0, 0.0);                                                                  // :80     e(i+1,0)
+    // Lanes outside the rhombus -- i > 2(M - r) for e(.,r), i > 2(M - r) - 1 for q(.,r+1) -- hold whatever the shifts bring
+    // and no entry inside ever reads them.  The fast flavour leaves them alone (8 selects per step less); the faithful one
+    // keeps them at 1 so that its scaled division never takes the out-of-line Annex-G recovery for a lane nobody reads.
+#if !UCF_FAST
+    if (lane > n2 - 1) q = cmake(1.0, 0.0);
+#endif
     for (int r = 1; r <= M; r++) {                                                              // :85-95
         const cplx qn = shfl_down1(q);
         cplx enew = cadd(csub(qn, q), en);
-        if (lane > 2 * (M - r)) enew = cmake(1.0, 0.0);      // outside the rhombus: keep lanes benign
+#if !UCF_FAST
+        if (lane > 2 * (M - r)) enew = cmake(1.0, 0.0);
+#endif
         if (lane == 0) {
             dcol[(size_t)(2 * r - 1) * pitch] = make_double2(-q.re, -q.im);                     // d(2r-1) = -q(0,r)   :100
             dcol[(size_t)(2 * r) * pitch] = make_double2(-enew.re, -enew.im);                   // d(2r)   = -e(0,r)   :101
         }
         if (r < M) {
             const cplx enn = shfl_down1(enew);
-            q = qd_quotient(qn, enn, enew);                                                     // :93
+            q = qd_quotient(qn, enn, enew, lane <= 2 * (M - r - 1) + 1);                        // :93
+#if !UCF_FAST
             if (lane > 2 * (M - r - 1) + 1) q = cmake(1.0, 0.0);
+#endif
             en = enn;
         }
     }
@@ -991,6 +1009,53 @@ UCF_DEV cplx wynn_regs(const cplx (&series)[NMAX], int nin, int* status)
     return acc;
 }
 
+#if UCF_FAST
+// The usual case of wynn_regs on its own: every lane of the wave has all its nin terms finite and no step of the table
+// comes near the absolute-epsilon exit (:172).  Then the bounds of the table are wave-uniform (scalar branches, no per-lane
+// predicates or selects) and the steps run unguarded, each lane only noting whether a guard WOULD have fired; if any did,
+// in any lane, the result is discarded and the caller runs the guarded table.  Same arithmetic, same bits as wynn_regs.
+template <int NMAX>
+UCF_DEV bool wynn_regs_clean(const cplx (&series)[NMAX], int nin, cplx* acc_out)
+{
+    cplx A[NMAX], B[NMAX];
+    bool bad = false;
+    cplx run = cmake(0.0, 0.0);
+#pragma unroll
+    for (int i = 1; i <= NMAX; i++) {                                                           // :140-163
+        A[i - 1] = cmake(0.0, 0.0);
+        B[i - 1] = cmake(0.0, 0.0);                                                             // :166
+        if (i <= nin) {
+            const cplx sv = series[i - 1];
+            bad |= !c_is_finite(sv);
+            run = (i == 1) ? sv : cadd(run, sv);
+            A[i - 1] = run;
+        }
+    }
+    if (nin < 4 || __builtin_amdgcn_ballot_w64(bad) != 0) return false;
+#pragma unroll
+    for (int j = 0; j <= NMAX - 2; j++) {                                                       // :169-181
+        const int count = nin - (j + 1);
+#pragma unroll
+        for (int m = 1; m <= NMAX - 1 - j; m++) {
+            if (m <= count) {
+                const cplx hi = (j & 1) ? B[m] : A[m];
+                const cplx lo = (j & 1) ? B[m - 1] : A[m - 1];
+                const cplx pv = (j & 1) ? A[m] : B[m];
+                const cplx denom = csub(hi, lo);
+                const double d2 = __builtin_fma(denom.re, denom.re, denom.im * denom.im);
+                bad |= !(d2 > UCF_EPS * UCF_EPS && d2 < 1.0e300);
+                const double r = fast_rcp(d2);
+                const cplx nv = cmake(__builtin_fma(denom.re, r, pv.re), __builtin_fma(-denom.im, r, pv.im));
+                if (j & 1) A[m - 1] = nv; else B[m - 1] = nv;
+            }
+        }
+    }
+    if (__builtin_amdgcn_ballot_w64(bad) != 0) return false;
+    *acc_out = A[1];
+    return true;
+}
+#endif
+
 // ------------------------------------------------------------- integration.f90:192-237
 // Per-lane Neville extrapolation to x = 0.  colC[(i*strideC)][lane] holds y(i+1) (destroyed),
 // colD is half-wave scratch.  x is wave-uniform.
@@ -1174,7 +1239,15 @@ UCF_DEV void finish_item(const ucf_dev_params& P, lds_c* accTS, lds_c* scr, cons
             }
             for (int part = 0; part < UCF_WAVE / PART; part++)
                 if ((lane / PART) == part && R > 1) finint = extrap_lane<PART>(accTS + (size_t)z * UCF_WAVE, nz, scr, P.hv, R, lane);
+#if UCF_FAST
+            // (the whole wave on the unguarded table when no lane needs a guard -- all areas zero in a lane counts as a guard)
+            if (__builtin_amdgcn_ballot_w64(!any) != 0 || !wynn_regs_clean<UCF_WYNN_REGS>(ser, nacc, &infint)) {
+                infint = cmake(0.0, 0.0);
+                if (any) infint = wynn_regs<UCF_WYNN_REGS>(ser, nacc, &wst);
+            }
+#else
             if (any) infint = wynn_regs<UCF_WYNN_REGS>(ser, nacc, &wst);
+#endif
         } else
         for (int part = 0; part < UCF_WAVE / PART; part++) {
             if ((lane / PART) == part) {
@@ -2157,6 +2230,7 @@ static int launch_transform_(const ucf_dev_params& dp, int nwork, int per_point,
     // an instantiation that knows nz = 1 at compile time: no depth loop, no running area in LDS (measured on C2: -2.4 %).
     // Only there: the unfolded and the finite-difference kernels LOSE 12 ... 46 % to it (C2pp 88 -> 100 ms, C4 237 -> 266,
     // C5 204 -> 297: the compiler hoists the depth's constants into registers those kernels do not have)
+    // (two depths known at compile time for the screened observation well of C3, 3-waves budget: -0.7 %, not taken)
 #ifndef UCF_NZC
 #define UCF_NZC(F, FO) (LAYOUT == 1 && (F) == 2 && (FO) ? 1 : 0)
 #endif
@@ -2195,8 +2269,11 @@ static int launch_transform_(const ucf_dev_params& dp, int nwork, int per_point,
             }
             // the screen terms need the registers: 4 waves/SIMD (128 VGPRs, ~60 spilled; 5 waves: -31 %); with two or more
             // depths per launch 3 waves/SIMD and no spills are 3 % faster (C3), with one depth 5 % slower (C2pp)
-            else if (dp.nz >= 2) UCF_LAUNCH_UNF(2, 3);
-            else UCF_LAUNCH_UNF(2, UCF_UNFOLD_WAVES);
+            else {
+                static const int unf_w = [] { const char* e = std::getenv("UCF_UNFOLD_WAVES_RT"); return e ? std::atoi(e) : 0; }();   // diagnostic: 3 or 4
+                if (unf_w == 3 || (unf_w != 4 && dp.nz >= 2)) UCF_LAUNCH_UNF(2, 3);
+                else UCF_LAUNCH_UNF(2, UCF_UNFOLD_WAVES);
+            }
             break;
         case 4: if (fold) UCF_LAUNCH_FOLD(4, 4); else UCF_LAUNCH_UNF(4, 4); break;
         }
