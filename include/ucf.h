@@ -23,8 +23,8 @@
  *     parameter objects, driver.f90:129-230): any number of host threads may call the drawdown entry points on ONE
  *     plan at the same time.  Everything a call writes lives in a workspace that the plan keeps PER HIP STREAM:
  *     calls on different streams share nothing and run concurrently; calls that name the same stream (the host
- *     entry points all use the default stream) are enqueued one after the other under the workspace's lock and
- *     execute in stream order.  The *_device entry points never synchronise; they allocate only when a workspace
+ *     point-list entry uses the default stream, the host grid entries a stream that the plan owns for its lifetime)
+ *     are enqueued one after the other under the workspace's lock and execute in stream order.  The *_device entry points never synchronise; they allocate only when a workspace
  *     must grow (outgrown buffers are kept until the stream has drained, never freed under a running kernel), and not
  *     at all after ucf_plan_reserve -- which is what capturing them into a hipGraph needs.
  *     What may NOT overlap with calls in flight on the same plan: ucf_plan_update, ucf_plan_set_mode,

@@ -5,10 +5,13 @@
 // the reference's summation order and need no cross-lane traffic.  What the 64 lanes are depends on the lane
 // layout (decode_item below): 64 consecutive TIMES of one radius and one Laplace index (grids, LAYOUT 1), 64 POINTS
 // of a list and one Laplace index (LAYOUT 3), or the Laplace samples p_m of one point (LAYOUT 0; chunks of 64 of
-// them for 2M+1 > 64, LAYOUT 2).  The abscissa loop has its own kernel (integrate_kernel / integrate_generic_kernel):
-// level sums in LDS ([slot][lane] complex, 16 B per lane -> conflict-free b128 accesses); when the loop is done the
+// them for 2M+1 > 64, LAYOUT 2).  The abscissa loop has its own kernel (integrate_kernel with the fast evaluators of
+// ucf_fastpath.h -- every model family has one; integrate_generic_kernel with the reference-order evaluators in the faithful
+// flavour): level sums in LDS ([slot][lane] complex, 16 B per lane -> conflict-free b128 accesses); when the loop is done the
 // level sums and the finished J0-interval areas go to the work item's STATE in HBM (1 KB coalesced per slot, ~15 KB
-// per item on the C2 settings -- deliberate traffic that buys the loop its occupancy).
+// per item on the C2 settings -- deliberate traffic that buys the loop its occupancy).  What depends on
+// the time and the Laplace index only -- the pumping-schedule multiplier lapTime(p) and the constants the fast evaluators
+// leave out of their samples -- comes from laptime_kernel, one value per (time, p) instead of one evaluation per work item.
 // finish_kernel reads the state back (Richardson/Neville and Wynn-epsilon per lane), writes the accelerated
 // transform totlap(r, z, m, t) (16 B each) and dehoog_*_kernel inverts it with lane = Laplace index: only de Hoog's
 // quotient-difference table needs neighbours (lane i+1: one DPP move per dword).  The abscissa tables (a, a J0(a rD)
