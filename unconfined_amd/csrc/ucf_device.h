@@ -2262,11 +2262,13 @@ static int launch_transform_(const ucf_dev_params& dp, int nwork, int per_point,
         case 1: if (fold) UCF_LAUNCH_FOLD(1, 4); else UCF_LAUNCH_UNF(1, 4); break;
         case 2:
             if (fold) {
-                // register budget by the waves the LDS footprint admits per SIMD (measured on C2: 51.6 / 50.3 ms at 5 / 6)
-                static const int force_w = [] { const char* e = std::getenv("UCF_FOLD_WAVES_RT"); return e ? std::atoi(e) : 0; }();   // diagnostic
+                // register budget: 5 waves per SIMD (96 VGPRs, 8 of them spilled around the abscissa loop) where the LDS
+                // footprint admits them.  Round 3, C2: 35.8 / 34.8 / 34.8 ms at 4 / 5 / 6 waves -- the sixth wave buys nothing
+                // any more and costs 16 more spilled registers per item (2 GB of scratch traffic per sweep); the 1/8 shard
+                // runs 5.29 against 5.33 ms.  UCF_FOLD_WAVES_RT (diagnostic): force 4, 5 or 6.
+                static const int force_w = [] { const char* e = std::getenv("UCF_FOLD_WAVES_RT"); return e ? std::atoi(e) : 0; }();
                 if (force_w == 4) UCF_LAUNCH_FOLD(2, 4);
-                else if (force_w == 5) UCF_LAUNCH_FOLD(2, 5);
-                else if (wlds * 24 <= 160 * 1024) UCF_LAUNCH_FOLD(2, 6);
+                else if (force_w == 6 && wlds * 24 <= 160 * 1024) UCF_LAUNCH_FOLD(2, 6);
                 else if (w5) UCF_LAUNCH_FOLD(2, UCF_FOLD_WAVES);
                 else UCF_LAUNCH_FOLD(2, 4);
             }
