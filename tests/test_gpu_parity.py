@@ -762,6 +762,27 @@ def test_random_parameter_sets_fast_vs_faithful():
             assert e_fast <= 30.0 * max(e_ref, 1e-10), (w, arb[w[1]])
 
 
+def test_random_parameter_sets_round3_evaluators():
+    """the same net over the families whose fast evaluators are new in round 3: Theis (model 0), Hantush with wellbore
+    storage (model 2: partially and fully penetrating, well / casing / observation-well radii and the shape factor moved),
+    Mishra-Neuman in Malama's closed form (model 6, MNtype 1: sorptive numbers and the unsaturated thickness moved)"""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_flavours
+    # (above the screen the reference's Hantush factor cancels -- up to O(1) errors against exact arithmetic, as for model 1 --
+    #  so that many model-2 sets are judged against the binary128 evaluation: the fast flavour is the accurate one there)
+    worst, judged = fuzz_flavours.run(nsets=40, seed=23, verbose=False, judge_above=1e-7, max_judged=40, models=(0, 2, 12, 16))
+    assert len(worst) >= 30
+    assert {w[2] for w in worst} == {0, 2, 6}
+    assert all(w[-1] for w in worst), [w for w in worst if not w[-1]]
+    arb = {j[0]: j for j in judged}
+    for w in worst:
+        if w[0] > 1e-7:
+            assert w[1] in arb, w
+            _, e_fast, e_faithful, e_ref = arb[w[1]]
+            assert e_fast <= 30.0 * max(e_ref, 1e-10), (w, arb[w[1]])
+
+
 def test_smoke_entry():
     import __graft_entry__ as g
     g.smoke()

@@ -1523,7 +1523,9 @@ integrate_kernel(const ucf_dev_params P0, int npts, int per_point, int nr, int n
         // (the pumping-schedule multiplier lapTime(p) is constant over the abscissae: the sums are formed without it and
         //  scaled when they leave the kernel -- one complex product per sample less)
         // times the constants the evaluators leave out: laptime_kernel formed it for every (row of tD, m)
-        const double2 ltv = ltab[(size_t)W.mlap * nrows + W.it];
+        // (lanes past the last Laplace sample -- LAYOUT 0 / 2, 2M+1 not a multiple of 64 -- compute on the last sample's entry:
+        //  the table has np rows)
+        const double2 ltv = ltab[(size_t)(W.mlap < P0.np ? W.mlap : P0.np - 1) * nrows + W.it];
         const cplx lt = cmake(ltv.x, ltv.y);
         const lane_consts LC = make_lane_consts(P, p, lt);
         double2* __restrict__ sti = state + (size_t)pt * state_slots(P0) * UCF_WAVE;
@@ -2202,7 +2204,10 @@ static int launch_transform_(const ucf_dev_params& dp, int nwork, int per_point,
         const dim3 igrid((unsigned)((((long long)nwork << lsplit) + UCF_IWPB - 1) / UCF_IWPB)), iblock(UCF_WAVE * UCF_IWPB);
         // lapTime(p) x constants for every (row of the call's tD, m): rows = the times of a grid / the points of a list.
         // The table lives behind the state of this launch's work items (the caller sized the buffer for it: lt_table_bytes)
-        const int nrows = (LAYOUT == 1) ? nt : (LAYOUT == 3 ? nt : (LAYOUT == 2 ? nwork / ((dp.np + UCF_WAVE - 1) / UCF_WAVE) : nwork));
+        // (LAYOUT 1: the nt times; 3: the nt points of the launch; 0 / 2: the points, or -- a small grid walked point by point,
+        //  per_point = 0 -- the time rows those points stand on: tD has no more entries than that)
+        const int npts_l = (LAYOUT == 2) ? nwork / ((dp.np + UCF_WAVE - 1) / UCF_WAVE) : nwork;
+        const int nrows = (LAYOUT == 1 || LAYOUT == 3) ? nt : (per_point ? npts_l : (npts_l + nr - 1) / nr);
         double* const d_ltab = d_state + (size_t)nwork * (dp.R + 1 + dp.nacc) * dp.nz * UCF_WAVE * 2;
         {
             const long long nlt = (long long)nrows * dp.np;

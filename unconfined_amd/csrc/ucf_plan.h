@@ -2,6 +2,7 @@
 #pragma once
 #include "../../include/ucf.h"
 #include <cstdio>
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 
@@ -70,6 +71,14 @@ static inline void ucf_tm_close(ucf_timers* tm, void* stream)
 }
 static inline void ucf_tm_mark(ucf_timers* tm, const char* name, void* stream)
 {
+    // UCF_TRACE_LAUNCHES=1 (diagnostic): wait for everything launched so far and name the kernel that comes next on stderr,
+    // so that the last line before a device fault names the kernel that faulted
+    static const bool trace = [] { const char* e = std::getenv("UCF_TRACE_LAUNCHES"); return e && *e && *e != '0'; }();
+    if (trace) {
+        const hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+        std::fprintf(stderr, "[ucf] stream %s; next: %s\n", e == hipSuccess ? "clean" : hipGetErrorString(e), name);
+        std::fflush(stderr);
+    }
     if (!tm) return;
     ucf_tm_close(tm, stream);
     if (tm->n >= UCF_MAX_TIMED) return;
