@@ -484,3 +484,51 @@ def test_parameter_batch_in_groups_equals_one_group(tmp_path):
     assert np.isfinite(res["one"]["h"]).all()
     for tag in ("two", "three"):
         assert np.array_equal(res[tag]["h"], res["one"]["h"]) and np.array_equal(res[tag]["dh"], res["one"]["dh"]), tag
+
+
+_GUARD_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+from golden_util import load_deck
+from unconfined_amd import engine
+rng = np.random.default_rng(5)
+out = {}
+for name in ("c1_theis", "hantush_lay2", "neuman74_partpen", "hstorage_partpen_lay2", "mishra_malama", "mishra_fd30"):
+    dk, ts, P = load_deck(name)
+    for mode in ("fast", "faithful"):
+        pl = engine.Plan(P, mode=mode)
+        zD = np.array([0.3, 0.93]); zl = pl.zlay(zD)
+        # a short list (lane = Laplace sample: 2M+1 < 64 live lanes), a long one (lane = point), a small grid walked point by
+        # point and one with enough times for lane = time
+        for tag, n in (("short", 48), ("long", 300)):
+            tD = 10.0 ** rng.uniform(-1, 4, n); rD = 10.0 ** rng.uniform(-1, 1, n)
+            h, dh = pl.drawdown(tD, rD, pl.split_vector(tD), zD, zl)
+            out["%s_%s_%s" % (name, mode, tag)] = h
+        for tag, nt, nr in (("smallgrid", 5, 3), ("grid", 70, 2)):
+            tD = np.logspace(-1, 3, nt); rD = np.linspace(0.3, 2.0, nr)
+            h, dh = pl.drawdown_grid(tD, pl.split_vector(tD), rD, zD, zl)
+            out["%s_%s_%s" % (name, mode, tag)] = h
+np.savez(sys.argv[2], **out)
+"""
+
+
+def test_no_kernel_reads_past_its_buffers(tmp_path):
+    """UCF_GUARD=1 puts every device buffer of the library at the END of its own pages: a kernel that reads past one runs
+    into the page behind it and the process dies of a memory access fault instead of silently using the allocator's slack
+    (round 3: the dead lanes of a lane = Laplace-sample launch read lapTime entries of samples that do not exist, found by a
+    fuzz run with two depths).  Every family, both flavours, every lane layout of lists and grids, two depths: the run must
+    end normally and give what the unguarded library gives"""
+    import os, subprocess, sys
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for tag, env in (("plain", {"UCF_GUARD": "0"}), ("guard", {"UCF_GUARD": "1"})):
+        out = str(tmp_path / f"{tag}.npz")
+        e = dict(os.environ); e.update(env)
+        subprocess.run([sys.executable, "-c", _GUARD_SCRIPT, root, out], check=True, env=e, timeout=600)
+        res[tag] = np.load(out)
+    assert len(res["plain"].files) == 6 * 2 * 4
+    for k in res["plain"].files:
+        assert np.array_equal(res["plain"][k], res["guard"][k], equal_nan=True), k

@@ -105,6 +105,7 @@ struct ucf_debug_rec {
 struct ucf_buffer {
     void* p = nullptr;
     size_t bytes = 0;
+    void* base = nullptr;          // what hipMalloc returned (== p unless UCF_GUARD places the buffer at the END of its pages)
 };
 struct ucf_workspace {
     void* stream = nullptr;
