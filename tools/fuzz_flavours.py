@@ -71,7 +71,7 @@ def run(nsets=40, seed=7, verbose=True, judge_above=1e-6, max_judged=6, models=(
             for (q, z) in np.argwhere(np.isnan(hf) != np.isnan(hg))[:3]:
                 ho, _ = oracle.batch(P, tD[q:q + 1], rD[q:q + 1], sv[q:q + 1], zD, zl)
                 ht, _ = oracle_q.batch(P, tD[q:q + 1], rD[q:q + 1], sv[q:q + 1], zD, zl, threads=8)
-                lost.append(bool(np.isnan(ho[0, z]) or abs(ho[0, z] - ht[0, z]) > 1e-6 * max(abs(ht[0, z]), 1e-4 * sc)))
+                lost.append(bool(np.isnan(ho[0, z]) or abs(ho[0, z] - ht[0, z]) > 1e-6 * abs(ht[0, z])))      # (not of the set's scale: that may be garbage itself)
             nan_ok = all(lost)
         worst.append((float(e[k]), i, model, full, float(dk2.kappa), float(rD[k[0]]), float(tD[k[0]]), float(zD[k[1]]), int(zl[k[1]]), bool(nan_ok)))
     worst.sort(reverse=True)
