@@ -271,7 +271,11 @@ int ucf_drawdown_batch_multi(ucf_plan* const* plans, int ngpu, int npts, const d
  * Fast-flavour plans of the same model and numerical settings (M, k/R, nacc/ord, alpha, tol, J0 split) -- the
  * fitting case: only hydraulic / geometric parameters vary -- share ONE launch sequence over (plan, point) work
  * items with per-plan parameter blocks in device memory; any other mix runs plan by plan on a small pool of
- * HIP streams so that the small launches overlap.  Either way the results equal the single-plan calls bit for bit.
+ * HIP streams so that the small launches overlap.  Plan by plan the results ARE the single-plan calls; the shared launch
+ * sequence runs other instantiations of the same kernels (parameter blocks in memory, often another lane layout), in
+ * which the compiler may contract a product and a sum into an FMA where the single-plan instantiation does not: same
+ * formulas, results equal to the rounding noise of the fast flavour -- bit for bit on most decks at their own settings,
+ * otherwise as far apart as either is from exact arithmetic (tests/test_gpu_contract.py judges that against binary128).
  * h, dh: [nplans][npts][nz]; dimensional (x Hc of each plan) unless dimensionless != 0. */
 int ucf_drawdown_multi(ucf_plan* const* plans, int nplans, int npts, const double* t, const double* r,
                        int nz, const double* z, int dimensionless, double* h, double* dh);

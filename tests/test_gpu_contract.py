@@ -532,3 +532,24 @@ def test_no_kernel_reads_past_its_buffers(tmp_path):
     assert len(res["plain"].files) == 6 * 2 * 4
     for k in res["plain"].files:
         assert np.array_equal(res["plain"][k], res["guard"][k], equal_nan=True), k
+
+
+def test_parameter_batches_of_random_shapes():
+    """ucf_drawdown_multi against every plan's own call over random numerical settings (M, k / R, accelerated zeros, GL order),
+    2 ... 9 plans, 1 ... 300 points, 1 ... 3 depths (tools/fuzz_shapes.py): the shared launch sequence runs other instantiations
+    of the kernels than a single plan's call, so the results agree to the fast flavour's rounding noise, not always bit for
+    bit (ucf.h) -- where the two are further apart than 1e-9 of the plan's scale (ill-resolved settings: 7 Gauss-Lobatto nodes,
+    M = 31 on the finite-difference model), the batch must be no further from the binary128 evaluation than 30 x the single
+    call is (or 1e-9)"""
+    import os, sys
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_shapes
+    done, not_equal, emax, judged = fuzz_shapes.run_multi(nsets=200, seed=6, verbose=False, judge_above=1e-9)
+    assert done >= 150
+    assert not_equal <= done // 3           # most sets are bit-equal
+    assert np.isfinite(emax) and emax < 1e-5
+    for (i, q, what, diff, e_batch, e_single) in judged:
+        assert e_batch <= max(30.0 * e_single, 1e-9), (i, q, what, diff, e_batch, e_single)
