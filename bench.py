@@ -296,16 +296,17 @@ def worker(args):
     if world > 1:
         gather_via = "torch.distributed all_gather_into_tensor" + ("" if backend == "nccl" else " (host-staged, rehearsal)")
         if backend == "nccl" and os.environ.get("UCF_BENCH_GATHER", "ucf") != "torch":
-            try:
-                idt = torch.zeros(128, dtype=torch.uint8, device=dev)
-                if rank == 0:
-                    idt.copy_(torch.frombuffer(bytearray(engine.comm_unique_id()), dtype=torch.uint8))
-                dist.broadcast(idt, 0)
+            def carry(buf):                       # the 128-byte id + validity byte, rank 0 -> all (every rank calls this)
+                t = buf.to(dev)
+                dist.broadcast(t, 0)
                 torch.cuda.synchronize()
-                lib_comm = engine.comm_create(bytes(idt.cpu().numpy().tobytes()), world, rank)
+                return t.cpu()
+            lib_comm, why = sharding.library_communicator(world, rank, dev, carry_id=carry,
+                                                          timeout=float(os.environ.get("UCF_BENCH_COMM_TIMEOUT", "120")))
+            if lib_comm:
                 gather_via = "ucf_drawdown_grid_allgather (in-place ncclAllGather on the launch stream, communicator from ucf_comm_create)"
-            except Exception as exc:
-                print(f"[bench] rank {rank}: the library's RCCL communicator is unavailable ({exc}); gathering with torch.distributed", file=sys.stderr)
+            else:
+                print(f"[bench] rank {rank}: the library's RCCL communicator is unavailable ({why}); gathering with torch.distributed", file=sys.stderr)
                 lib_comm = None
             ok_all = torch.tensor([1 if lib_comm else 0], device=dev)
             dist.all_reduce(ok_all, op=dist.ReduceOp.MIN)          # all ranks or none

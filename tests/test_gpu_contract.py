@@ -553,3 +553,20 @@ def test_parameter_batches_of_random_shapes():
     assert np.isfinite(emax) and emax < 1e-5
     for (i, q, what, diff, e_batch, e_single) in judged:
         assert e_batch <= max(30.0 * e_single, 1e-9), (i, q, what, diff, e_batch, e_single)
+
+
+def test_library_communicator_helper_one_rank(engine):
+    """sharding.library_communicator (what bench.py --gpus N calls on every rank): id + validity byte through the host's
+    transport, ucf_comm_create on a helper thread with the rank's device current and a time limit.  One rank here (RCCL
+    refuses two on one device); the transport is called only for world > 1"""
+    import torch
+    from unconfined_amd import sharding
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    called = []
+    comm, why = sharding.library_communicator(1, 0, torch.device("cuda:0"), carry_id=lambda b: called.append(1) or b, timeout=60.0)
+    assert comm and why is None and not called
+    engine.comm_destroy(comm)
+    # a transport that delivers an invalid id (rank 0 could not draw one): every rank gets (0, reason), nobody calls create
+    comm, why = sharding.library_communicator(2, 1, torch.device("cuda:0"), carry_id=lambda b: b * 0, timeout=5.0)
+    assert comm == 0 and "id" in why

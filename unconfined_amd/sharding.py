@@ -45,3 +45,52 @@ def allgather_rows_(full, nt: int, row_elems: int, world: int, rank: int, group=
         mine = mine.clone()            # gloo does not take an input that aliases the output
     dist.all_gather_into_tensor(full, mine, group=group)
     return full
+
+
+def library_communicator(world: int, rank: int, device, carry_id=None, timeout: float = 120.0):
+    """The library's own RCCL communicator for ``ucf_drawdown_grid_allgather`` (``ucf_comm_unique_id`` on rank 0,
+    ``ucf_comm_create`` everywhere), made so that no rank can be left waiting for another:
+
+    * rank 0 draws the 128-byte id; ``carry_id(buf129)`` -- the host's transport, e.g. a ``torch.distributed`` broadcast of
+      a uint8 tensor from rank 0 -- carries it to the others TOGETHER with a validity byte, and is called on every rank
+      whether or not the draw succeeded (a rank that skipped it would leave the others inside the broadcast);
+    * ``ncclCommInitRank`` is a collective: it runs on a helper thread (with the rank's device current -- the HIP device is
+      per thread) and is given ``timeout`` seconds; a rank that is still inside after that reports failure and leaves the
+      thread behind rather than hang the job.
+
+    Returns ``(comm, error)``: the communicator handle, or ``0`` and the reason.  The caller still has to agree over its own
+    transport that EVERY rank got one (all or none) before the first collective."""
+    import threading
+    import torch
+    from . import engine
+    buf = torch.zeros(129, dtype=torch.uint8)
+    err = None
+    if rank == 0:
+        try:
+            buf[:128] = torch.frombuffer(bytearray(engine.comm_unique_id()), dtype=torch.uint8)
+            buf[128] = 1
+        except Exception as exc:          # no RCCL in the process and none to load
+            err = f"ucf_comm_unique_id: {exc}"
+    if carry_id is not None and world > 1:
+        buf = carry_id(buf)
+    if int(buf[128]) != 1:
+        return 0, err or "rank 0 could not draw a communicator id"
+    uid = bytes(buf[:128].cpu().numpy().tobytes())
+    box = {}
+
+    def make():
+        try:
+            if device is not None:
+                torch.cuda.set_device(device)
+            box["comm"] = engine.comm_create(uid, world, rank)
+        except Exception as exc:
+            box["err"] = f"ucf_comm_create: {exc}"
+
+    th = threading.Thread(target=make, name="ucf-comm-create", daemon=True)
+    th.start()
+    th.join(timeout)
+    if th.is_alive():
+        return 0, f"ucf_comm_create did not return within {timeout:.0f} s"
+    if "comm" in box:
+        return box["comm"], None
+    return 0, box.get("err", "ucf_comm_create failed")
