@@ -1488,9 +1488,12 @@ integrate_kernel(const ucf_dev_params P0, int npts, int per_point, int nr, int n
     }
     __syncthreads();
     const lds_c* sct = lds;
-    lds_c* const wlds = lds + UCF_SC_ENTRIES + (size_t)wv * (R + 1) * nz * UCF_WAVE;
+    // (NZC = 1, 2: the running areas live in registers and the wave's LDS holds the level sums only -- for two depths at
+    //  R = 4 that is 8 instead of 10 KB per wave, which is what lets a fourth wave per SIMD in: 4 workgroups of 38 KB per CU)
+    const int lslots = (NZC ? R : R + 1) * nz;
+    lds_c* const wlds = lds + UCF_SC_ENTRIES + (size_t)wv * lslots * UCF_WAVE;
     lds_c* accTS = wlds;                                    // [R][nz]  level sums
-    lds_c* accCur = wlds + (size_t)R * nz * UCF_WAVE;       // [nz]     area of the J0 interval being integrated
+    lds_c* accCur = wlds + (size_t)R * nz * UCF_WAVE;       // [nz]     area of the J0 interval being integrated (NZC = 0 only)
     // A work item may be cut into 2^lsplit parts of whole quadrature units (the tanh-sinh part, then the J0 intervals: every
     // level sum and every interval area is formed by ONE part, in the reference's order -- same bits whatever the cut):
     // small launches (a shard of a strong-scaling run) then still fill the chip and end with a short tail.
@@ -1530,7 +1533,7 @@ integrate_kernel(const ucf_dev_params P0, int npts, int per_point, int nr, int n
         const lane_consts LC = make_lane_consts(P, p, lt);
         double2* __restrict__ sti = state + (size_t)pt * state_slots(P0) * UCF_WAVE;
         double2* __restrict__ areas = sti + (size_t)(R + 1) * nz * UCF_WAVE;
-        for (int s = 0; s < (R + 1) * nz; s++) lds_st(wlds, s, lane, cmake(0.0, 0.0));
+        for (int s = 0; s < lslots; s++) lds_st(wlds, s, lane, cmake(0.0, 0.0));
         fast_common F;
         sc_ctx_init(F.sc, sct, UCF_KV(FAMILY, FOLD));
         // the closure's unscaled reciprocal (fast_common_terms) wants |xi| = |eta| |xifac| far from overflow: an item with a
@@ -1544,8 +1547,8 @@ integrate_kernel(const ucf_dev_params P0, int npts, int per_point, int nr, int n
         int n = n0;
         double2 aa = row[n0 < nabs ? n0 : 0];
         int m = 0, jj = n0 > N ? (n0 - N) / ngl : 0;   // Gauss-Lobatto node and J0 interval of abscissa n >= N
-        cplx acc0 = cmake(0.0, 0.0);              // running area of the interval: a register when nz = 1,
-        for (; n < nlim; n++) {                   // else accCur[z] in LDS
+        cplx acc0 = cmake(0.0, 0.0), acc1 = cmake(0.0, 0.0);      // running area of the interval: registers when nz = 1 (or
+        for (; n < nlim; n++) {                   // NZC = 2: two depths known at compile time), else accCur[z] in LDS
             const double2 nxt = row[n + 1 < nabs ? n + 1 : n];
             const bool ts = n < N;
             F.sc.salt = n;
@@ -1567,8 +1570,10 @@ integrate_kernel(const ucf_dev_params P0, int npts, int per_point, int nr, int n
                         const int slot = (j - 1) * nz + z;
                         lds_st(accTS, slot, lane, cadd(lds_ld(accTS, slot, lane), rscale(wl, val)));
                     }
-                } else if (nz == 1) {
+                } else if (nz == 1 || (NZC == 2 && z == 0)) {
                     acc0 = cmake(__builtin_fma(fz.re, aa.y, acc0.re), __builtin_fma(fz.im, aa.y, acc0.im));       // :201-202
+                } else if (NZC == 2) {
+                    acc1 = cmake(__builtin_fma(fz.re, aa.y, acc1.re), __builtin_fma(fz.im, aa.y, acc1.im));
                 } else {
                     const cplx a1 = lds_ld(accCur, z, lane);
                     lds_st(accCur, z, lane, cmake(__builtin_fma(fz.re, aa.y, a1.re), __builtin_fma(fz.im, aa.y, a1.im)));
@@ -1580,11 +1585,12 @@ integrate_kernel(const ucf_dev_params P0, int npts, int per_point, int nr, int n
                 const double hib = P.j0z[sv + jj] / rD;
                 const double hw = (hib - lob) / 2.0;
                 for (int z = 0; z < nz; z++) {
-                    const cplx ar = cmul(rscale(hw, nz == 1 ? acc0 : lds_ld(accCur, z, lane)), lt);
+                    const cplx run = (nz == 1 || (NZC == 2 && z == 0)) ? acc0 : (NZC == 2 ? acc1 : lds_ld(accCur, z, lane));
+                    const cplx ar = cmul(rscale(hw, run), lt);
                     areas[(size_t)(jj * nz + z) * UCF_WAVE + lane] = make_double2(ar.re, ar.im);
-                    if (nz != 1) lds_st(accCur, z, lane, cmake(0.0, 0.0));
+                    if (nz != 1 && NZC != 2) lds_st(accCur, z, lane, cmake(0.0, 0.0));
                 }
-                acc0 = cmake(0.0, 0.0);
+                acc0 = acc1 = cmake(0.0, 0.0);
                 m = 0;
                 jj++;
             }
@@ -1596,11 +1602,12 @@ integrate_kernel(const ucf_dev_params P0, int npts, int per_point, int nr, int n
         // travels and the parts of an item need not agree on one.  ndone[pt] was set to nabs by the launcher; the smallest
         // hand-over point of the item's parts counts, the part that lowers it first lists the item.
         if (sub == 0) {
-            for (int z = 0; z < nz; z++) lds_st(accCur, z, lane, cmake(0.0, 0.0));
-            for (int s = 0; s < (R + 1) * nz; s++) {
+            for (int s = 0; s < R * nz; s++) {
                 const cplx v = cmul(lds_ld(wlds, s, lane), lt);
                 sti[(size_t)s * UCF_WAVE + lane] = make_double2(v.re, v.im);
             }
+            // (the slots of the running areas: nothing travels in them, point_kernel starts its interval afresh)
+            for (int s = R * nz; s < (R + 1) * nz; s++) sti[(size_t)s * UCF_WAVE + lane] = make_double2(0.0, 0.0);
         }
 #ifdef UCF_TIMELINE      /* into the (unread) running-area slot: lane 0 = (start, end) in shader clocks, lane 1 = (HW_ID, part) */
         if (sub == 0) {
@@ -2224,8 +2231,10 @@ static int launch_transform_(const ucf_dev_params& dp, int nwork, int per_point,
             }
 #undef UCF_LAUNCH_LT
         }
+        static const bool nzc2_on = [] { const char* e = std::getenv("UCF_NZC2"); return !e || *e != '0'; }();      // diagnostic: 0 = off
 #define UCF_LAUNCH_I4(F, W, FO, L3, NZC)                                                                       \
     do {                                                                                                       \
+        const size_t ilds = ((size_t)((NZC) ? dp.R : dp.R + 1) * dp.nz * UCF_WAVE * sizeof(lds_c)) * UCF_IWPB + UCF_SC_ENTRIES * sizeof(lds_c); \
         if (ilds > 64 * 1024)                                                                                  \
             (void)hipFuncSetAttribute((const void*)integrate_kernel<F, LAYOUT, W, MULTI, FO, L3, NZC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ilds); \
         std::snprintf(kname, sizeof(kname), UCF_STR(UCF_NS) "::integrate_kernel<%d, %d, %d, %s, %s, %s, %d>", F, LAYOUT, W, MULTI ? "true" : "false", FO ? "true" : "false", L3 ? "true" : "false", NZC); \
@@ -2238,13 +2247,20 @@ static int launch_transform_(const ucf_dev_params& dp, int nwork, int per_point,
     // an instantiation that knows nz = 1 at compile time: no depth loop, no running area in LDS (measured on C2: -2.4 %).
     // Only there: the unfolded and the finite-difference kernels LOSE 12 ... 46 % to it (C2pp 88 -> 100 ms, C4 237 -> 266,
     // C5 204 -> 297: the compiler hoists the depth's constants into registers those kernels do not have)
-    // (two depths known at compile time for the screened observation well of C3, 3-waves budget: -0.7 %, not taken)
+    // Launches of TWO depths in that layout (a screened observation well, C3; every pair of depths of a contour-style call,
+    // which the host walks two at a time) run NZC = 2 in every family: the two running areas in registers, so that the wave's
+    // LDS holds the level sums alone and a fourth workgroup fits the CU (C3 130.5 -> 115.2 ms per launch; 21-depth calls on
+    // 128 x 64 points: +5 ... +27 %, Theis +52 %; tools/gpu_depths.sh).  UCF_NZC2=0 (diagnostic) turns it off.
 #ifndef UCF_NZC
 #define UCF_NZC(F, FO) (LAYOUT == 1 && (F) == 2 && (FO) ? 1 : 0)
+#endif
+#ifndef UCF_NZC2
+#define UCF_NZC2(F, FO) (LAYOUT == 1 ? 2 : 0)
 #endif
 #define UCF_LAUNCH_I3(F, W, FO, L3)                                                                            \
     do {                                                                                                       \
         if (UCF_NZC(F, FO) && dp.nz == 1) UCF_LAUNCH_I4(F, W, FO, L3, UCF_NZC(F, FO));                         \
+        else if (UCF_NZC2(F, FO) && dp.nz == 2 && nzc2_on) UCF_LAUNCH_I4(F, W, FO, L3, UCF_NZC2(F, FO));        \
         else UCF_LAUNCH_I4(F, W, FO, L3, 0);                                                                   \
     } while (0)
         // a depth above the screen top anywhere in the call (in any plan of a parameter batch)?
@@ -2255,9 +2271,15 @@ static int launch_transform_(const ucf_dev_params& dp, int nwork, int per_point,
         if (lay3) UCF_LAUNCH_I3(F, W, false, true);                                                            \
         else UCF_LAUNCH_I3(F, W, false, false);                                                                \
     } while (0)
-        const bool w5 = wlds * 20 <= 160 * 1024;
         // fully penetrating pumping well (every plan of a parameter batch must be): the screen terms are compiled out
         const bool fold = dp.fold_dD && dp.fold_lD1 && !MULTI;
+        // two depths of the water-table family in the lane = time layout: running areas in registers (NZC = 2), level sums
+        // alone in LDS -- at R = 4 a workgroup then needs 38 instead of 46 KB and FOUR of them fit a CU (measured on C3:
+        // 130.5 -> 115.2 ms per launch with the 4-waves register budget; 127.3 ms with 3)
+        const bool nzc2 = UCF_NZC2(2, false) != 0 && fam == 2 && nzc2_on && dp.nz == 2;
+        const size_t wlds_eff = (nzc2 || (UCF_NZC(2, true) != 0 && fam == 2 && fold && dp.nz == 1))
+                                    ? (size_t)dp.R * dp.nz * UCF_WAVE * sizeof(lds_c) + UCF_SC_ENTRIES * sizeof(lds_c) / UCF_IWPB : wlds;
+        const bool w5 = wlds_eff * 20 <= 160 * 1024;
         // (parameter batches: the water-table and Hantush families only, ucf_drawdown_multi)
         if (MULTI && (fam == 0 || fam == 3 || fam == 5)) return UCF_ERR_UNSUPPORTED;
         switch (fam) {
@@ -2273,7 +2295,7 @@ static int launch_transform_(const ucf_dev_params& dp, int nwork, int per_point,
                 // runs 5.29 against 5.33 ms.  UCF_FOLD_WAVES_RT (diagnostic): force 4, 5 or 6.
                 static const int force_w = [] { const char* e = std::getenv("UCF_FOLD_WAVES_RT"); return e ? std::atoi(e) : 0; }();
                 if (force_w == 4) UCF_LAUNCH_FOLD(2, 4);
-                else if (force_w == 6 && wlds * 24 <= 160 * 1024) UCF_LAUNCH_FOLD(2, 6);
+                else if (force_w == 6 && wlds_eff * 24 <= 160 * 1024) UCF_LAUNCH_FOLD(2, 6);
                 else if (w5) UCF_LAUNCH_FOLD(2, UCF_FOLD_WAVES);
                 else UCF_LAUNCH_FOLD(2, 4);
             }
@@ -2281,7 +2303,7 @@ static int launch_transform_(const ucf_dev_params& dp, int nwork, int per_point,
             // depths per launch 3 waves/SIMD and no spills are 3 % faster (C3), with one depth 5 % slower (C2pp)
             else {
                 static const int unf_w = [] { const char* e = std::getenv("UCF_UNFOLD_WAVES_RT"); return e ? std::atoi(e) : 0; }();   // diagnostic: 3 or 4
-                if (unf_w == 3 || (unf_w != 4 && dp.nz >= 2)) UCF_LAUNCH_UNF(2, 3);
+                if (unf_w == 3 || (unf_w != 4 && dp.nz >= 2 && !nzc2)) UCF_LAUNCH_UNF(2, 3);
                 else UCF_LAUNCH_UNF(2, UCF_UNFOLD_WAVES);
             }
             break;
