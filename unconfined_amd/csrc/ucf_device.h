@@ -2255,7 +2255,7 @@ static int launch_transform_(const ucf_dev_params& dp, int nwork, int per_point,
 #define UCF_NZC(F, FO) (LAYOUT == 1 && (F) == 2 && (FO) ? 1 : 0)
 #endif
 #ifndef UCF_NZC2
-#define UCF_NZC2(F, FO) (LAYOUT == 1 ? 2 : 0)
+#define UCF_NZC2(F, FO) ((LAYOUT == 1 || LAYOUT == 3) ? 2 : 0)
 #endif
 #define UCF_LAUNCH_I3(F, W, FO, L3)                                                                            \
     do {                                                                                                       \
