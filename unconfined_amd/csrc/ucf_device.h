@@ -1746,8 +1746,10 @@ finish_kernel(const ucf_dev_params P, int npts, int per_point, int nr, int nsv, 
 #ifndef UCF_DH_WAVES
 #define UCF_DH_WAVES 4
 #endif
-template <int TU>          // (a template only so that two translation units may hold it)
-__global__ void __launch_bounds__(UCF_WAVE, UCF_DH_WAVES)
+// BIG: more Laplace samples than lanes (M > 31) -- the chunked rhombus of dehoog_big and its registers get their own
+// instantiation, so that the usual one is not allocated for them
+template <int TU, bool BIG>          // (TU: a template parameter only so that two translation units may hold the kernel)
+__global__ void __launch_bounds__(UCF_WAVE, BIG ? 4 : UCF_DH_WAVES)
 dehoog_tiles_kernel(const ucf_dev_params P, int nt, int nr, int ir0, int nrc, const double* __restrict__ tDv,
                     const double2* __restrict__ totlap, double* __restrict__ hout, double* __restrict__ dhout,
                     ucf_stats* st)
@@ -1770,7 +1772,7 @@ dehoog_tiles_kernel(const ucf_dev_params P, int nt, int nr, int ir0, int nrc, co
                 if (tt < ncur) lds[m * pitch + tt] = src[(size_t)m * nt + it0 + tt];
             }
             __syncthreads();
-            if (np <= UCF_WAVE) {
+            if constexpr (!BIG) {
                 for (int tt = 0; tt < ncur; tt++) {
                     const double tD = tDv[it0 + tt];
                     const double tee = 2.0 * tD;
@@ -1988,8 +1990,12 @@ int launch_dehoog_tiles_hook(const ucf_dev_params& dp, int n, const double* d_tD
 {
     const long long ntl = (n + UCF_DH_TILE - 1) / UCF_DH_TILE;
     const size_t dlds = 2 * (size_t)dp.np * (UCF_DH_TILE + 1) * sizeof(lds_c) + 2 * UCF_DH_TILE * sizeof(int);
-    hipLaunchKernelGGL(dehoog_tiles_kernel<1>, dim3((unsigned)ntl), dim3(UCF_WAVE), dlds, (hipStream_t)stream, dp, n, 1, 0, 1, d_tD,
-                       (const double2*)d_totlap, d_h, d_dh, (ucf_stats*)nullptr);
+    if (dp.np <= UCF_WAVE)
+        hipLaunchKernelGGL((dehoog_tiles_kernel<1, false>), dim3((unsigned)ntl), dim3(UCF_WAVE), dlds, (hipStream_t)stream, dp, n, 1, 0, 1, d_tD,
+                           (const double2*)d_totlap, d_h, d_dh, (ucf_stats*)nullptr);
+    else
+        hipLaunchKernelGGL((dehoog_tiles_kernel<1, true>), dim3((unsigned)ntl), dim3(UCF_WAVE), dlds, (hipStream_t)stream, dp, n, 1, 0, 1, d_tD,
+                           (const double2*)d_totlap, d_h, d_dh, (ucf_stats*)nullptr);
     return hipGetLastError() == hipSuccess ? UCF_OK : UCF_ERR_HIP;
 }
 #endif
@@ -2452,9 +2458,14 @@ int launch_grid_transposed(const ucf_dev_params& dp, int nt, int nr, int ir0, in
     if (rc) return rc;
     const long long ntl = (long long)nrc * ((nt + UCF_DH_TILE - 1) / UCF_DH_TILE);
     const size_t dlds = 2 * (size_t)dp.np * (UCF_DH_TILE + 1) * sizeof(lds_c) + 2 * UCF_DH_TILE * sizeof(int);
-    ucf_tm_mark(tm, UCF_STR(UCF_NS) "::dehoog_tiles_kernel<1>", s);
-    hipLaunchKernelGGL(dehoog_tiles_kernel<1>, dim3((unsigned)(ntl > 0x7fffffffLL ? 0x7fffffff : ntl)), dim3(UCF_WAVE), dlds, s, dp, nt, nr, ir0,
-                       nrc, d_tD, (const double2*)d_totlap, d_h, d_dh, d_stats);
+    const dim3 dgrid((unsigned)(ntl > 0x7fffffffLL ? 0x7fffffff : ntl));
+    if (dp.np <= UCF_WAVE) {
+        ucf_tm_mark(tm, UCF_STR(UCF_NS) "::dehoog_tiles_kernel<1, false>", s);
+        hipLaunchKernelGGL((dehoog_tiles_kernel<1, false>), dgrid, dim3(UCF_WAVE), dlds, s, dp, nt, nr, ir0, nrc, d_tD, (const double2*)d_totlap, d_h, d_dh, d_stats);
+    } else {
+        ucf_tm_mark(tm, UCF_STR(UCF_NS) "::dehoog_tiles_kernel<1, true>", s);
+        hipLaunchKernelGGL((dehoog_tiles_kernel<1, true>), dgrid, dim3(UCF_WAVE), dlds, s, dp, nt, nr, ir0, nrc, d_tD, (const double2*)d_totlap, d_h, d_dh, d_stats);
+    }
     ucf_tm_close(tm, s);
     return hipGetLastError() == hipSuccess ? UCF_OK : UCF_ERR_HIP;
 }
@@ -2477,8 +2488,12 @@ int launch_points_lanes(const ucf_dev_params& dp, int npts, int ppp, const doubl
     if (rc) return rc;
     const long long ntl = (npts + UCF_DH_TILE - 1) / UCF_DH_TILE;
     const size_t dlds = 2 * (size_t)dp.np * (UCF_DH_TILE + 1) * sizeof(lds_c) + 2 * UCF_DH_TILE * sizeof(int);
-    hipLaunchKernelGGL(dehoog_tiles_kernel<3>, dim3((unsigned)ntl), dim3(UCF_WAVE), dlds, s, dp, npts, 1, 0, 1, d_tD,
-                       (const double2*)d_totlap, d_h, d_dh, d_stats);
+    if (dp.np <= UCF_WAVE)
+        hipLaunchKernelGGL((dehoog_tiles_kernel<3, false>), dim3((unsigned)ntl), dim3(UCF_WAVE), dlds, s, dp, npts, 1, 0, 1, d_tD,
+                           (const double2*)d_totlap, d_h, d_dh, d_stats);
+    else
+        hipLaunchKernelGGL((dehoog_tiles_kernel<3, true>), dim3((unsigned)ntl), dim3(UCF_WAVE), dlds, s, dp, npts, 1, 0, 1, d_tD,
+                           (const double2*)d_totlap, d_h, d_dh, d_stats);
     return hipGetLastError() == hipSuccess ? UCF_OK : UCF_ERR_HIP;
 }
 #endif
