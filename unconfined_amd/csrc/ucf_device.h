@@ -1211,15 +1211,21 @@ UCF_DEV work_item decode_item(const ucf_dev_params& P, int pt, int lane, int per
 // (LAYOUT 0).  accTS: [R][nz] level sums in LDS; the finished areas come from LDS (accGL) or global memory.
 // PART lanes of the wave work at a time on the scratch columns scr ([max(2 nacc, R)][PART]).
 #define UCF_WYNN_REGS 12      /* terms the register-resident Wynn-epsilon of finish_kernel holds */
-template <int LAYOUT, int PART, bool WREG = false>
+// MODE (finish_kernel, WREG, fast flavour): 0 = everything here; 1 = the unguarded epsilon table only -- a (item, depth) in
+// which some lane needs one of the reference's guards (:297-311: a zero difference, the early exit, an all-zero series) is
+// appended to the list `defer` = [count | pt * nz + z ...] and left alone; 2 = the depths [z0, z1) of a listed item with the
+// guarded table.  Split so that the kernel every item runs is not allocated for the table almost none needs (168 -> 125
+// VGPRs, 3 -> 4 waves per SIMD; C2: 1.20 -> 0.9 ms)
+template <int LAYOUT, int PART, bool WREG = false, int MODE = 0>
 UCF_DEV void finish_item(const ucf_dev_params& P, lds_c* accTS, lds_c* scr, const lds_c* accGL,
                          const double2* __restrict__ areas, double arg, const work_item& W, int pt, double tD, double tee,
                          cplx p, ucf_stats* st, int nt, int ir0, double2* __restrict__ totlap, double* __restrict__ hout,
-                         double* __restrict__ dhout)
+                         double* __restrict__ dhout, int z0 = 0, int z1 = -1, int* __restrict__ defer = nullptr)
 {
     const int lane = threadIdx.x;
     const int nz = P.nz, R = P.R, nacc = P.nacc;
-    for (int z = 0; z < nz; z++) {
+    if (z1 < 0) z1 = nz;
+    for (int z = z0; z < z1; z++) {
         for (int j = 0; j < R; j++) {
             const int slot = j * nz + z;
             lds_st(accTS, slot, lane, rscale(arg / 2.0, lds_ld(accTS, slot, lane)));            // :135,154
@@ -1244,7 +1250,13 @@ UCF_DEV void finish_item(const ucf_dev_params& P, lds_c* accTS, lds_c* scr, cons
                 if ((lane / PART) == part && R > 1) finint = extrap_lane<PART>(accTS + (size_t)z * UCF_WAVE, nz, scr, P.hv, R, lane);
 #if UCF_FAST
             // (the whole wave on the unguarded table when no lane needs a guard -- all areas zero in a lane counts as a guard)
-            if (__builtin_amdgcn_ballot_w64(!any) != 0 || !wynn_regs_clean<UCF_WYNN_REGS>(ser, nacc, &infint)) {
+            if (MODE == 2) {
+                if (any) infint = wynn_regs<UCF_WYNN_REGS>(ser, nacc, &wst);
+            } else if (__builtin_amdgcn_ballot_w64(!any) != 0 || !wynn_regs_clean<UCF_WYNN_REGS>(ser, nacc, &infint)) {
+                if (MODE == 1) {
+                    if (lane == 0) defer[1 + atomicAdd(&defer[0], 1)] = pt * nz + z;
+                    continue;                              // (nothing of this depth has left the wave yet)
+                }
                 infint = cmake(0.0, 0.0);
                 if (any) infint = wynn_regs<UCF_WYNN_REGS>(ser, nacc, &wst);
             }
@@ -1701,12 +1713,14 @@ integrate_generic_kernel(const ucf_dev_params P, int npts, int per_point, int nr
 // Tail of every work item integrate_kernel completed (all of them outside the overflow regime): state ->
 // finish_item.  Model independent and small, so it runs at full occupancy; PART is chosen at launch from the
 // LDS footprint ((R+1) nz slots of level sums + max(2 nacc, R) scratch columns of PART lanes).
-template <int LAYOUT, int PART, bool WREG>
-__global__ void __launch_bounds__(UCF_WAVE, (LAYOUT == 0 || WREG) ? 3 : 4)      // LAYOUT 0 carries de Hoog, WREG the epsilon table
+// MODE 1 / 2 (finish_item): the pass over all items with the unguarded epsilon table, then the pass over the (item, depth)
+// pairs it listed in `defer` with the guarded one.
+template <int LAYOUT, int PART, bool WREG, int MODE = 0>
+__global__ void __launch_bounds__(UCF_WAVE, (LAYOUT == 0 || (WREG && MODE != 1)) ? 3 : 4)      // LAYOUT 0 carries de Hoog, WREG the guarded epsilon table
 finish_kernel(const ucf_dev_params P, int npts, int per_point, int nr, int nsv, int svmin,
               const double* __restrict__ tDv, const double* __restrict__ rDv, const int* __restrict__ svv,
               double* __restrict__ hout, double* __restrict__ dhout, ucf_stats* st, int nt, int ir0,
-              double2* __restrict__ totlap, const double2* __restrict__ state, const int* __restrict__ ndone)
+              double2* __restrict__ totlap, const double2* __restrict__ state, const int* __restrict__ ndone, int* __restrict__ defer)
 {
     extern __shared__ lds_c lds[];
     const int lane = threadIdx.x;
@@ -1714,8 +1728,11 @@ finish_kernel(const ucf_dev_params P, int npts, int per_point, int nr, int nsv, 
     const int nabs = P.N + nacc * P.ngl;
     lds_c* accTS = lds;
     lds_c* scr = lds + (size_t)R * nz * UCF_WAVE;
-    for (int pt = blockIdx.x; pt < npts; pt += gridDim.x) {
-        if (ndone[pt] < nabs) continue;
+    const int nloop = (MODE == 2) ? defer[0] : npts;
+    for (int wi = blockIdx.x; wi < nloop; wi += gridDim.x) {
+        const int pt = (MODE == 2) ? defer[1 + wi] / nz : wi;
+        const int zsel = (MODE == 2) ? defer[1 + wi] % nz : 0;
+        if (MODE != 2 && ndone[pt] < nabs) continue;
         const work_item W = decode_item<LAYOUT>(P, pt, lane, per_point, nr, nt, ir0, npts);
         const double tD = tDv[W.it], rD = rDv[W.ir];
         const int sv = (LAYOUT == 1) ? svmin : svv[W.it];
@@ -1725,8 +1742,8 @@ finish_kernel(const ucf_dev_params P, int npts, int per_point, int nr, int nsv, 
         const double arg = P.j0z[sv - 1] / rD;                                                  // driver.f90:120
         const double2* __restrict__ sti = state + (size_t)pt * state_slots(P) * UCF_WAVE;
         for (int s = 0; s < R * nz; s++) lds[s * UCF_WAVE + lane] = sti[(size_t)s * UCF_WAVE + lane];
-        finish_item<LAYOUT, PART, WREG>(P, accTS, scr, nullptr, sti + (size_t)(R + 1) * nz * UCF_WAVE, arg, W, pt, tD, tee, p, st, nt, ir0,
-                                        totlap, hout, dhout);
+        finish_item<LAYOUT, PART, WREG, MODE>(P, accTS, scr, nullptr, sti + (size_t)(R + 1) * nz * UCF_WAVE, arg, W, pt, tD, tee, p, st, nt, ir0,
+                                              totlap, hout, dhout, zsel, (MODE == 2) ? zsel + 1 : nz, (MODE == 1) ? defer : nullptr);
     }
 }
 
@@ -2360,21 +2377,34 @@ static int launch_transform_(const ucf_dev_params& dp, int nwork, int per_point,
         if (part != 16 && part != 32 && part != 64) part = (flds(64) <= 40 * 1024) ? 64 : (flds(32) <= 40 * 1024) ? 32 : 16;
         const size_t fl = flds(part);
         if (fl > 160 * 1024) return UCF_ERR_UNSUPPORTED;
-#define UCF_LAUNCH_F(PART, WR)                                                                                 \
+#define UCF_LAUNCH_FM(PART, WR, MODE, GRID)                                                                     \
     do {                                                                                                       \
         if (fl > 64 * 1024)                                                                                    \
-            (void)hipFuncSetAttribute((const void*)finish_kernel<LAYOUT, PART, WR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fl); \
-        std::snprintf(kname, sizeof(kname), UCF_STR(UCF_NS) "::finish_kernel<%d, %d, %s>", LAYOUT, PART, WR ? "true" : "false"); \
+            (void)hipFuncSetAttribute((const void*)finish_kernel<LAYOUT, PART, WR, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fl); \
+        std::snprintf(kname, sizeof(kname), UCF_STR(UCF_NS) "::finish_kernel<%d, %d, %s, %d>", LAYOUT, PART, WR ? "true" : "false", MODE); \
         ucf_tm_mark(tm, kname, s);                                                                             \
-        hipLaunchKernelGGL((finish_kernel<LAYOUT, PART, WR>), dim3((unsigned)nwork), block, fl, s, dp, nwork, per_point, nr, nsv, svmin, \
+        hipLaunchKernelGGL((finish_kernel<LAYOUT, PART, WR, MODE>), dim3((unsigned)(GRID)), block, fl, s, dp, nwork, per_point, nr, nsv, svmin, \
                            d_tD, d_rD, d_sv, d_h, d_dh, d_stats, nt, ir0, (double2*)d_totlap, (const double2*)d_state, \
-                           (const int*)d_ndone);                                                               \
+                           (const int*)d_ndone, d_defer);                                                      \
+    } while (0)
+        // fast flavour, epsilon table in registers: the pass with the unguarded table over all items, then the guarded one over
+        // what that pass listed (d_defer: [count | pt * nz + z ...] behind the two lists of integrate_kernel)
+        int* const d_defer = d_ndone + 2 * (size_t)nwork + 1;
+        const bool two_pass = UCF_FAST && wreg;
+        if (two_pass) (void)hipMemsetAsync(d_defer, 0, sizeof(int), s);
+#define UCF_LAUNCH_F(PART, WR)                                                                                 \
+    do {                                                                                                       \
+        if constexpr (UCF_FAST && (WR)) {                                                                      \
+            UCF_LAUNCH_FM(PART, WR, 1, nwork);                                                                 \
+            UCF_LAUNCH_FM(PART, WR, 2, (nwork < 1024 ? nwork : 1024));                                         \
+        } else UCF_LAUNCH_FM(PART, WR, 0, nwork);                                                              \
     } while (0)
         if (wreg) { if (part == 64) UCF_LAUNCH_F(64, true); else if (part == 32) UCF_LAUNCH_F(32, true); else UCF_LAUNCH_F(16, true); }
         else if (part == 64) UCF_LAUNCH_F(64, false);
         else if (part == 32) UCF_LAUNCH_F(32, false);
         else UCF_LAUNCH_F(16, false);
 #undef UCF_LAUNCH_F
+#undef UCF_LAUNCH_FM
         if (hipGetLastError() != hipSuccess) return UCF_ERR_HIP;
         if (kind == 2) { ucf_tm_close(tm, s); return UCF_OK; }      // the generic evaluators leave nothing unfinished
         // the unfinished ones (overflow regime): point_kernel over the list integrate_kernel left
