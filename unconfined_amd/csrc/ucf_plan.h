@@ -20,6 +20,7 @@ struct ucf_dev_params {
     int M, np, k, N, R, nacc, ngl, nz;
     int tab_premul;        // the abscissa table's Gauss-Lobatto entries carry their quadrature weight (fast flavour; abscissa_kernel)
     int nj0z, any_lay3;    // any_lay3: some depth of the launch (of any plan of a parameter batch) lies above the screen top
+    int any_lay1;          // ... below the screen bottom
     int nz_out, z_off;     // depths of the whole call / offset of this launch's chunk: out index = pt*nz_out + z_off + z
     double timePar[2];
     double kappa, alphaD, beta;
