@@ -2400,7 +2400,7 @@ static int launch_transform_(const ucf_dev_params& dp, int nwork, int per_point,
     do {                                                                                                       \
         if constexpr (UCF_FAST && (WR)) {                                                                      \
             UCF_LAUNCH_FM(PART, WR, 1, nwork);                                                                 \
-            UCF_LAUNCH_FM(PART, WR, 2, (nwork < 1024 ? nwork : 1024));                                         \
+            UCF_LAUNCH_FM(PART, WR, 2, (nwork < 12288 ? nwork : 12288));      /* (4 rounds of resident waves; an empty list costs ~6 us) */ \
         } else UCF_LAUNCH_FM(PART, WR, 0, nwork);                                                              \
     } while (0)
         if (wreg) { if (part == 64) UCF_LAUNCH_F(64, true); else if (part == 32) UCF_LAUNCH_F(32, true); else UCF_LAUNCH_F(16, true); }
