@@ -13,13 +13,14 @@ One "step" = one pass of the hot path over the whole synthetic sweep that is res
 N > 1: one process per GPU over RCCL.  Under torch.distributed.run (RANK / WORLD_SIZE in the
 environment) this file is a rank; started plainly with --gpus N it launches its N ranks itself
 (fresh child processes, before anything here touches a GPU) and fails if RCCL does not see N ranks.
-  --scaling strong (default)  the FIXED sweep of the workload (C2 1024x256, C4 4096x1024, ...) is cut into N contiguous
+  --scaling weak (default)    every rank owns a full nt x nr sweep (the metric's 1024 x 256 on C2) of its own block of
+                              radii, nt x nr*N in all: the points are independent, per-GPU work is fixed as N grows.
+  --scaling strong            the FIXED sweep of the workload (C2 1024x256, C4 4096x1024, ...) is cut into N contiguous
                               blocks of time rows (ucf_shard_rows: the reference's i loop, driver.f90:100); every
                               rank computes its rows in place in the full-size result arrays and one in-place
                               all-gather per array completes them on every rank (the reference's single output).
-  --scaling weak              every rank owns a full nt x nr sweep of its own block of radii (nt x nr*N in all).
-No data-path collective in either; the gather is inside the timed step.  The other mode is measured after the
-timed region and reported under "other_scaling".
+No data-path collective in either; the final gather is inside the timed step.  The other mode is measured after the
+line of the timed region is complete and reported under "other_scaling" (under a time limit: the line is never lost to it).
 
 The JSON line carries
   roofline      : bound = fp64 VALU (this path is neither HBM- nor MFMA-bound).  `achieved` = fp64 flop the
@@ -147,7 +148,7 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--mode", default=os.environ.get("UCF_BENCH_MODE", "fast"), choices=["faithful", "fast"])
-    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"])
+    ap.add_argument("--scaling", default="weak", choices=["strong", "weak"])
     ap.add_argument("--workload", default="c2", choices=["c2", "c2pp", "c3", "c4", "c5", "c1", "hstorage", "mnm"])
     ap.add_argument("--nt", type=int, default=0)
     ap.add_argument("--nr", type=int, default=0)
@@ -293,7 +294,11 @@ def worker(args):
     # torch.distributed instead (same layout; also what happens, loudly, if the library's communicator cannot be made)
     lib_comm = None
     gather_via = "none"
-    if world > 1:
+
+    def make_lib_comm():
+        nonlocal lib_comm, gather_via
+        if world == 1 or lib_comm:
+            return
         gather_via = "torch.distributed all_gather_into_tensor" + ("" if backend == "nccl" else " (host-staged, rehearsal)")
         if backend == "nccl" and os.environ.get("UCF_BENCH_GATHER", "ucf") != "torch":
             def carry(buf):                       # the 128-byte id + validity byte, rank 0 -> all (every rank calls this)
@@ -395,6 +400,8 @@ def worker(args):
 
     if args.scaling == "weak":
         alloc_weak()
+    else:
+        make_lib_comm()
     main_step = step_strong if args.scaling == "strong" else step_weak
     elapsed, kernels = timed(main_step, args.steps, args.warmup, True)
     pts_main = (nt * nr if args.scaling == "strong" else nt * nr * world)
@@ -416,23 +423,56 @@ def worker(args):
         ok = bool(torch.isfinite(d_out[0]).all().item())
         if world > 1:
             ok = ok and bool(torch.equal(d_all[2 * rank:2 * rank + 2], d_out))
+    main_gather = gather_via if args.scaling == "strong" else ("torch.distributed all_gather_into_tensor" if world > 1 else "none")
 
-    other = None
-    if world > 1 and not args.no_other_scaling:
-        if args.scaling == "strong":
-            alloc_weak()
-            e2, _ = timed(step_weak, args.steps, 1, False)
-            other = {"scaling": "weak", "value": nt * nr * world * args.steps / e2, "ms_per_step": e2 / args.steps * 1e3,
-                     "points_per_step": nt * nr * world}
-        else:
-            e2, _ = timed(step_strong, args.steps, 1, False)
-            other = {"scaling": "strong", "value": nt * nr * args.steps / e2, "ms_per_step": e2 / args.steps * 1e3,
-                     "points_per_step": nt * nr}
+    def other_scaling(line):
+        """The other scaling mode, AFTER the line of the timed region is complete (rank 0 holds it): if this second
+        measurement does not come back -- the library's own N-rank communicator runs here for the first time on a node
+        this repository never had -- the line is printed without it instead of being lost with the run."""
+        import threading
 
-    if lib_comm:
-        torch.cuda.synchronize()
-        engine.comm_destroy(lib_comm)
+        def bail():
+            if rank == 0:
+                line["other_scaling"] = {"error": "did not finish within its time limit; the timed region above is unaffected"}
+                print(json.dumps(line), flush=True)
+            os._exit(0)
+        dog = threading.Timer(float(os.environ.get("UCF_BENCH_OTHER_TIMEOUT", "240")), bail)
+        dog.daemon = True
+        dog.start()
+        try:
+            if args.scaling == "strong":
+                alloc_weak()
+                e2, _ = timed(step_weak, args.steps, 1, False)
+                other = {"scaling": "weak", "value": nt * nr * world * args.steps / e2, "ms_per_step": e2 / args.steps * 1e3,
+                         "points_per_step": nt * nr * world, "gather": "torch.distributed all_gather_into_tensor"}
+            else:
+                make_lib_comm()
+                e2, _ = timed(step_strong, args.steps, 1, False)
+                hh = d_full[0][: nt * row]
+                chk = torch.stack([hh.sum(), d_full[1][: nt * row].sum()])
+                if backend != "nccl":
+                    chk = chk.cpu()
+                lo_, hi_ = chk.clone(), chk.clone()
+                dist.all_reduce(lo_, op=dist.ReduceOp.MIN)
+                dist.all_reduce(hi_, op=dist.ReduceOp.MAX)
+                other = {"scaling": "strong", "value": nt * nr * args.steps / e2, "ms_per_step": e2 / args.steps * 1e3,
+                         "points_per_step": nt * nr, "gather": gather_via,
+                         "results_finite_and_gather_consistent": bool(torch.isfinite(hh).all().item()) and bool(torch.equal(lo_, hi_))}
+        except Exception as exc:
+            other = {"error": f"{exc.__class__.__name__}: {exc}"}
+        dog.cancel()
+        if lib_comm:
+            torch.cuda.synchronize()
+            engine.comm_destroy(lib_comm)
+        return other
+
+    want_other = world > 1 and not args.no_other_scaling
     if rank != 0:
+        if want_other:
+            other_scaling(None)
+        elif lib_comm:
+            torch.cuda.synchronize()
+            engine.comm_destroy(lib_comm)
         if world > 1:
             dist.destroy_process_group()
         return 0
@@ -482,7 +522,7 @@ def worker(args):
                    "points_per_step": pts_main, "points_per_gpu": pts_launch, "mode": args.mode, "layout": args.layout,
                    "partition": ("contiguous blocks of time rows (ucf_shard_rows), in-place all-gather of h and dh" if args.scaling == "strong"
                                  else "one block of radii per rank, all-gather of [h; dh]") + f", one rank per GPU, backend {backend if world > 1 else 'none'}",
-                   "gather": gather_via if args.scaling == "strong" else ("torch.distributed all_gather_into_tensor" if world > 1 else "none"),
+                   "gather": main_gather,
                    "launcher": "self (bench.py spawned its ranks)" if os.environ.get("UCF_BENCH_SELF_LAUNCHED") else ("torch.distributed.run" if world > 1 else "single process"),
                    "build_id": build_id, "results_finite_and_gather_consistent": ok},
         "roofline": {"bound": "fp64_valu", "achieved": drow.get("executed_TFLOPs"), "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s",
@@ -505,8 +545,11 @@ def worker(args):
                              "achieved_GBs": alg_bytes / (dom[1] * 1e-3) * 1e-9, "peak_GBs": PEAK_HBM_GBS,
                              "frac": alg_bytes / (dom[1] * 1e-3) * 1e-9 / PEAK_HBM_GBS}},
     }
-    if other:
-        line["other_scaling"] = other
+    if want_other:
+        line["other_scaling"] = other_scaling(line)
+    elif lib_comm:
+        torch.cuda.synchronize()
+        engine.comm_destroy(lib_comm)
     if world == 1 and not args.no_cpu:
         # the box shows every hardware thread of the host but a 1-GPU job owns a 16-core share; the
         # reference's OpenMP regions are 48-63 iterations long, so more threads only add overhead
@@ -540,6 +583,21 @@ def worker(args):
             line["accuracy_vs_cpu_ref"] = {"error": str(exc)}
         cb.pop("_rows", None); cb.pop("_radii", None)
         line["cpu_baseline"] = cb
+        # the same sweep through the HOST-array entry of the boundary (ucf_drawdown_grid: numpy arrays in, h and dh copied back
+        # over PCIe, the call returns when they are there) -- never `value`, reported beside it
+        try:
+            rD_h = np.ascontiguousarray(10.0 ** engine.linspace(-1.0, 1.0, nr))
+            plan.drawdown_grid(tD, sv_t, rD_h, zD, zl)
+            nh = 3
+            t0 = time.perf_counter()
+            for _ in range(nh):
+                hh_, dd_ = plan.drawdown_grid(tD, sv_t, rD_h, zD, zl)
+            eh_ = (time.perf_counter() - t0) / nh
+            line["host_entry_pcie_inclusive"] = {"value": nt * nr / eh_, "unit": "points/s", "ms_per_step": eh_ * 1e3, "steps": nh,
+                                                 "entry": "ucf_drawdown_grid (host arrays; inputs H2D, h and dh D2H, synchronous)",
+                                                 "finite": bool(np.isfinite(hh_).all() and np.isfinite(dd_).all())}
+        except Exception as exc:
+            line["host_entry_pcie_inclusive"] = {"error": str(exc)}
         line["gpu_over_cpu"] = value / cb["value"] if args.workload == "c2" else None
     if world == 1 and not args.no_other_workloads and not args.no_cpu and args.workload == "c2" and not args.nt and not args.nr:
         # the other BASELINE.json configurations (and the models outside them) at FULL size on this GPU, after the timed

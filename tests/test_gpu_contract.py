@@ -534,6 +534,62 @@ def test_no_kernel_reads_past_its_buffers(tmp_path):
         assert np.array_equal(res["plain"][k], res["guard"][k], equal_nan=True), k
 
 
+_PARTS_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+from golden_util import load_deck
+from unconfined_amd import engine
+rng = np.random.default_rng(11)
+out = {}
+# every family of the fast flavour; one deck whose small radii leave the fast evaluators (hand-over inside a part)
+for name in ("c1_theis", "hantush_lay2", "c2_neuman74_fullpen", "neuman74_partpen", "c4_malama_partpen", "hstorage_partpen_lay2",
+             "mishra_malama", "mishra_fd30"):
+    dk, ts, P = load_deck(name)
+    pl = engine.Plan(P, mode="fast")
+    for nz, zD in ((1, np.array([0.6])), (2, np.array([0.3, 0.93]))):
+        zl = pl.zlay(zD)
+        tD = np.logspace(-1, 4, 128); rD = np.array([0.02, 0.11, 0.7, 3.0, 9.0])      # lane = time; rD = 0.02: overflow regime
+        h, dh, st = pl.drawdown_grid(tD, pl.split_vector(tD), rD, zD, zl, with_stats=True)
+        out["%s_grid_nz%d_h" % (name, nz)] = h; out["%s_grid_nz%d_dh" % (name, nz)] = dh
+        n = 320                                                                         # lane = point
+        tDl = 10.0 ** rng.uniform(-1, 4, n); rDl = 10.0 ** rng.uniform(-1.7, 1, n)
+        h, dh = pl.drawdown(tDl, rDl, pl.split_vector(tDl), zD, zl)
+        out["%s_list_nz%d_h" % (name, nz)] = h; out["%s_list_nz%d_dh" % (name, nz)] = dh
+    pl.close()
+np.savez(sys.argv[2], **out)
+"""
+
+
+def test_results_do_not_depend_on_how_work_items_are_cut(tmp_path):
+    """integrate_kernel may run a work item in 1, 2, 4 or 8 parts of whole quadrature units (small launches in two, the last
+    round of every launch in finer ones, launch_transform_): every level sum and every interval area is formed by one part in
+    the reference's order, a part that leaves the fast evaluators hands over at the start of its interval -- so the cut must
+    not change a bit of h or dh.  Child processes (the knobs are read once per process): whole items, everything in 2 / 4 / 8
+    parts, and the default; grids (lane = time) and lists (lane = point), one and two depths, every family"""
+    import os, subprocess, sys
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cuts = (("whole", {"UCF_NSPLIT": "1", "UCF_TAIL_LSPLIT": "0"}),
+            ("halves", {"UCF_NSPLIT": "2", "UCF_TAIL_LSPLIT": "0"}),
+            ("quarters", {"UCF_NSPLIT": "1", "UCF_TAIL_LSPLIT": "2", "UCF_TAIL_ITEMS": "100000000"}),
+            ("eighths", {"UCF_NSPLIT": "8"}),
+            ("mixed", {"UCF_NSPLIT": "1", "UCF_TAIL_LSPLIT": "3", "UCF_TAIL_ITEMS": "37"}),
+            ("default", {}))
+    res = {}
+    for tag, env in cuts:
+        out = str(tmp_path / f"{tag}.npz")
+        e = {k: v for k, v in os.environ.items() if k not in ("UCF_NSPLIT", "UCF_TAIL_LSPLIT", "UCF_TAIL_ITEMS")}
+        e.update(env)
+        subprocess.run([sys.executable, "-c", _PARTS_SCRIPT, root, out], check=True, env=e, timeout=600)
+        res[tag] = np.load(out)
+    assert len(res["whole"].files) == 8 * 2 * 4
+    for tag, _ in cuts[1:]:
+        for k in res["whole"].files:
+            assert np.array_equal(res["whole"][k], res[tag][k], equal_nan=True), (tag, k)
+
+
 def test_parameter_batches_of_random_shapes():
     """ucf_drawdown_multi against every plan's own call over random numerical settings (M, k / R, accelerated zeros, GL order),
     2 ... 9 plans, 1 ... 300 points, 1 ... 3 depths (tools/fuzz_shapes.py): the shared launch sequence runs other instantiations

@@ -1465,6 +1465,10 @@ laptime_kernel(const ucf_dev_params P0, int nrows, const double* __restrict__ tD
 #ifndef UCF_UNFOLD_WAVES
 #define UCF_UNFOLD_WAVES 4
 #endif
+// parts (2^k) of the work items of the last round of a launch (launch_transform_)
+#ifndef UCF_TAIL_LSPLIT_DEFAULT
+#define UCF_TAIL_LSPLIT_DEFAULT 3
+#endif
 // constants of sincos_tab_ / exp_tab_ kept in VGPRs (sc_ctx::kv)
 #ifndef UCF_KV
 #define UCF_KV(FAMILY, FOLD) ((FAMILY) == 4 ? 0 : 4)
@@ -1479,7 +1483,7 @@ integrate_kernel(const ucf_dev_params P0, int npts, int per_point, int nr, int n
                  const double* __restrict__ tDv, const double* __restrict__ rDv, const int* __restrict__ svv,
                  const double2* __restrict__ tab, int nt, int ir0, double2* __restrict__ state, int* __restrict__ ndone,
                  int* __restrict__ todo, const ucf_dev_params* __restrict__ Pv, int ppp, int pbase, int lsplit,
-                 const double2* __restrict__ ltab, int nrows)
+                 const double2* __restrict__ ltab, int nrows, int nheadw, int nworkw)
 {
     extern __shared__ lds_c lds[];
 #ifdef UCF_K1_ASSUME
@@ -1506,12 +1510,18 @@ integrate_kernel(const ucf_dev_params P0, int npts, int per_point, int nr, int n
     lds_c* const wlds = lds + UCF_SC_ENTRIES + (size_t)wv * lslots * UCF_WAVE;
     lds_c* accTS = wlds;                                    // [R][nz]  level sums
     lds_c* accCur = wlds + (size_t)R * nz * UCF_WAVE;       // [nz]     area of the J0 interval being integrated (NZC = 0 only)
-    // A work item may be cut into 2^lsplit parts of whole quadrature units (the tanh-sinh part, then the J0 intervals: every
+    // A work item may be cut into parts of whole quadrature units (the tanh-sinh part, then the J0 intervals: every
     // level sum and every interval area is formed by ONE part, in the reference's order -- same bits whatever the cut):
     // small launches (a shard of a strong-scaling run) then still fill the chip and end with a short tail.
-    const int nsplit = 1 << lsplit;
-    for (int wi = blockIdx.x * UCF_IWPB + wv; wi < npts * nsplit; wi += gridDim.x * UCF_IWPB) {
-        const int pt = wi >> lsplit, sub = wi & (nsplit - 1);
+    // The first nhead items run in 2^lsplit parts, the LAST npts - nhead items -- the ones the dispatcher hands out when
+    // nothing is left to refill a SIMD, and a wave does not run faster on an emptier SIMD -- in 2^ltail: the drain of the
+    // launch lasts as long as a part, not as an item, and only those items pay a part's set-up more than once.
+    // (lsplit = lsplit | ltail << 8; nheadw = nhead << lsplit work units of the leading items, nworkw = all of them)
+    for (int wi = blockIdx.x * UCF_IWPB + wv; wi < nworkw; wi += gridDim.x * UCF_IWPB) {
+        const bool tail = wi >= nheadw;
+        const int ls = tail ? (lsplit >> 8) : (lsplit & 255), nsplit = 1 << ls;
+        const int wj = tail ? wi - nheadw : wi;
+        const int pt = (tail ? (nheadw >> (lsplit & 255)) : 0) + (wj >> ls), sub = wj & (nsplit - 1);
         // abscissae [n0, n1) of part `sub`: boundaries at N + j ngl, j the nearest to an even cut of the nabs abscissae
         auto part_bound = [&](int k) {
             if (k <= 0) return 0;
@@ -2228,10 +2238,27 @@ static int launch_transform_(const ucf_dev_params& dp, int nwork, int per_point,
         while (lsplit < 1 && ((long long)nwork << lsplit) < 8LL * 256 * 4 * 6) lsplit++;
         if (force_split > 0) { lsplit = 0; while ((1 << (lsplit + 1)) <= force_split && lsplit < 3) lsplit++; }
         if ((1 << lsplit) > dp.nacc + 1) lsplit = 0;
+        // ... and the last items of EVERY launch run in finer parts: ntail = one round of resident waves, 2^ltail parts each
+        // (UCF_TAIL_ITEMS / UCF_TAIL_LSPLIT: diagnostic overrides; UCF_TAIL_LSPLIT=0 turns the finer tail off).  Measured
+        // (tools/gpu_tail_parts.sh): C2 34.78 -> 34.64 ms, its 1/8 shard 4.835 -> 4.79 ms with 8 parts for the last 5 120
+        // items (2 or 4 parts, or 10 240 items: the same within 0.2 %) -- a small gain: a wave on an emptying SIMD does
+        // speed up enough to hide most of the quantisation of a launch into rounds.  Bit-neutral like every cut
+        // (test_results_do_not_depend_on_how_work_items_are_cut).
+        static const int tail_ls_env = [] { const char* e = std::getenv("UCF_TAIL_LSPLIT"); return e ? std::atoi(e) : -1; }();
+        static const int tail_items_env = [] { const char* e = std::getenv("UCF_TAIL_ITEMS"); return e ? std::atoi(e) : -1; }();
+        int ltail = tail_ls_env >= 0 ? tail_ls_env : UCF_TAIL_LSPLIT_DEFAULT;
+        if (ltail > 3) ltail = 3;
+        while (ltail > 0 && (1 << ltail) > dp.nacc + 1) ltail--;
+        if (ltail < lsplit) ltail = lsplit;
+        int ntail = tail_items_env >= 0 ? tail_items_env : 256 * 4 * 5;
+        if (ntail > nwork) ntail = nwork;
+        const int nhead = (ltail == lsplit) ? nwork : nwork - ntail;
+        const long long nworkw = ((long long)nhead << lsplit) + ((long long)(nwork - nhead) << ltail);
+        if (nworkw > 0x7fffffffLL) return UCF_ERR_UNSUPPORTED;
         // per workgroup: the sin/cos table + UCF_IWPB waves' accumulators; wlds = the footprint one wave accounts for
         const size_t wlds = (size_t)(dp.R + 1) * dp.nz * UCF_WAVE * sizeof(lds_c) + UCF_SC_ENTRIES * sizeof(lds_c) / UCF_IWPB;
         const size_t ilds = wlds * UCF_IWPB;
-        const dim3 igrid((unsigned)((((long long)nwork << lsplit) + UCF_IWPB - 1) / UCF_IWPB)), iblock(UCF_WAVE * UCF_IWPB);
+        const dim3 igrid((unsigned)((nworkw + UCF_IWPB - 1) / UCF_IWPB)), iblock(UCF_WAVE * UCF_IWPB);
         // lapTime(p) x constants for every (row of the call's tD, m): rows = the times of a grid / the points of a list.
         // The table lives behind the state of this launch's work items (the caller sized the buffer for it: lt_table_bytes)
         // (LAYOUT 1: the nt times; 3: the nt points of the launch; 0 / 2: the points, or -- a small grid walked point by point,
@@ -2263,8 +2290,8 @@ static int launch_transform_(const ucf_dev_params& dp, int nwork, int per_point,
         std::snprintf(kname, sizeof(kname), UCF_STR(UCF_NS) "::integrate_kernel<%d, %d, %d, %s, %s, %s, %d, %s>", F, LAYOUT, W, MULTI ? "true" : "false", FO ? "true" : "false", L3 ? "true" : "false", NZC, L1 ? "true" : "false"); \
         ucf_tm_mark(tm, kname, s);                                                                             \
         hipLaunchKernelGGL((integrate_kernel<F, LAYOUT, W, MULTI, FO, L3, NZC, L1>), igrid, iblock, ilds, s, dp, nwork, per_point, nr, nsv, svmin, \
-                           d_tD, d_rD, d_sv, (const double2*)d_tab, nt, ir0, (double2*)d_state, d_ndone, d_todo, d_params, ppp, pbase, lsplit, \
-                           (const double2*)d_ltab, nrows);                                                     \
+                           d_tD, d_rD, d_sv, (const double2*)d_tab, nt, ir0, (double2*)d_state, d_ndone, d_todo, d_params, ppp, pbase, lsplit | (ltail << 8), \
+                           (const double2*)d_ltab, nrows, nhead << lsplit, (int)nworkw);                                                     \
     } while (0)
     // launches of ONE depth of the fully penetrating water-table family in the lane = time layout (the headline sweep) run
     // an instantiation that knows nz = 1 at compile time: no depth loop, no running area in LDS (measured on C2: -2.4 %).
