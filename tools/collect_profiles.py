@@ -56,7 +56,8 @@ prof["what"] = ("rocprofv3 --pmc passes of tools/gpu_final.sh over `python3 benc
                 "MI355X, full-size sweeps); averages per dispatch.  fp64_flop_per_launch = 64 lanes x (2 FMA + ADD + MUL + TRANS) wave instructions; "
                 "valu_busy = SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs); hbm_bytes_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) KB "
                 "(MI355X_MICROARCH.md: FETCH_SIZE reports half of wide coalesced reads on gfx950; separate passes, the TCC counters do not fit one); "
-                "*_per_wave_abscissa = instructions / SQ_WAVES / abscissae of the workload (integrate kernels only)")
+                "*_per_wave_abscissa = instructions / work items of the launch (64 times x radius x Laplace sample) / abscissae of the workload (integrate kernels only; "
+                "a work item is one wave except in the last round of a launch, whose items run in 8 parts)")
 for W in WORKLOADS:
     ks = sorted(glob.glob(os.path.join(G, f"fin_{W}_trace", "*", "*kernel_stats.csv")), key=os.path.getmtime)
     if ks:
@@ -67,6 +68,10 @@ for W in WORKLOADS:
     if not line or not sq:
         continue
     nabs = int(re.search(r"\((\d+) abscissae", line["config"]["workload"]).group(1))
+    # work items of one launch of an integrate kernel (lane = time layout of the bench sweeps: 64 times x one radius x one
+    # Laplace sample, all depths).  NOT SQ_WAVES: the last round of a launch runs its items in several parts, one wave each
+    M_ = int(re.search(r"M=(\d+)", line["config"]["workload"]).group(1))
+    items = line["roofline"]["points_per_kernel_launch"] / 64.0 * (2 * M_ + 1)
     kern = {}
     for k in sorted(set(sq) | set(f64) | set(fe) | set(wr)):
         if "ucf_" not in k:
@@ -77,13 +82,14 @@ for W in WORKLOADS:
             arith = c["SQ_INSTS_VALU_FMA_F64"] + c["SQ_INSTS_VALU_ADD_F64"] + c["SQ_INSTS_VALU_MUL_F64"] + c["SQ_INSTS_VALU_TRANS_F64"]
             e["fp64_flop_per_launch"] = 64.0 * (arith + c["SQ_INSTS_VALU_FMA_F64"])
             if "integrate" in k and c.get("SQ_WAVES"):
-                e["fp64_arith_per_wave_abscissa"] = arith / c["SQ_WAVES"] / nabs
+                e["fp64_arith_per_wave_abscissa"] = arith / items / nabs
         # (only for the long kernels: GRBM_GUI_ACTIVE of a 2 ms kernel is dominated by ramp-up and drain and the ratio overshoots 1)
         if c.get("GRBM_GUI_ACTIVE") and "SQ_ACTIVE_INST_VALU" in c and ("integrate" in k or "point_kernel" in k):
             e["valu_busy"] = min(1.0, c["SQ_ACTIVE_INST_VALU"] * 4 / (c["GRBM_GUI_ACTIVE"] / 8 * 1024))
         if "integrate" in k and c.get("SQ_WAVES") and "SQ_INSTS_VALU" in c:
-            e["valu_per_wave_abscissa"] = c["SQ_INSTS_VALU"] / c["SQ_WAVES"] / nabs
-            e["salu_per_wave_abscissa"] = c["SQ_INSTS_SALU"] / c["SQ_WAVES"] / nabs
+            e["valu_per_wave_abscissa"] = c["SQ_INSTS_VALU"] / items / nabs
+            e["salu_per_wave_abscissa"] = c["SQ_INSTS_SALU"] / items / nabs
+            e["work_items_per_launch"], e["waves_per_launch"] = items, c["SQ_WAVES"]
         if k in fe or k in wr:
             f_, w_ = fe.get(k, {}).get("FETCH_SIZE", 0.0), wr.get(k, {}).get("WRITE_SIZE", 0.0)
             e["FETCH_SIZE_KB"], e["WRITE_SIZE_KB"] = f_, w_

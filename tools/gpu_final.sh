@@ -8,7 +8,11 @@
 #     rocprofv3 --pmc FETCH_SIZE                  -- (same)       (separate passes: the TCC counters do not fit one)
 #     rocprofv3 --pmc WRITE_SIZE                  -- (same)
 #   then the GPU tests, the default bench line (with the CPU baseline) and the faithful-flavour line.
-# WORKLOADS="c2 c4" restricts the first part; SKIP_TESTS=1 skips the second.
+# WORKLOADS="c2 c4" restricts the first part; SKIP_TESTS=1 skips the second (but for the bench lines of BENCH_WORKLOADS).
+# A call on the box is limited to 20 minutes, so a pass is two calls (the counters of a workload and its bench line in the same one):
+#   WORKLOADS="c2 c2pp c3 c1" BENCH_WORKLOADS="c2pp c3 c1" bash tools/gpu_final.sh
+#   WORKLOADS="c4 c5 hstorage mnm" BENCH_WORKLOADS="c4 c5 hstorage mnm" SKIP_TESTS=1 bash tools/gpu_final.sh
+# and tools/collect_profiles.py once more in the build container over the merged gpurun_out/.
 set -o pipefail
 mkdir -p gpurun_out
 R=$GRAFT_REPO_ROOT
@@ -30,11 +34,16 @@ done
 cd $R
 # the counters of THIS build become profiles/pmc_r03.json on the box, so that the bench lines below carry their roofline
 python3 tools/collect_profiles.py ${TAG:-r03} > gpurun_out/collect.log 2>&1; cp profiles/pmc_r03.json gpurun_out/pmc_r03.json
-[ -n "$SKIP_TESTS" ] && exit 0
+if [ -n "$SKIP_TESTS" ]; then      # second call of a pass cut in two (a call is limited to 20 minutes): the bench lines of its workloads only
+  for W in ${BENCH_WORKLOADS:-}; do
+    timeout -k 10 600 python bench.py --no-cpu --workload $W --steps 3 > gpurun_out/bench_$W.log 2> gpurun_out/bench_$W.err; echo "[bench $W] rc=$?"
+  done
+  exit 0
+fi
 timeout -k 10 1000 python -m pytest tests -m gpu -q --no-header -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1; rc=$?; echo "[pytest] rc=$rc $(tail -1 gpurun_out/pytest_gpu.log)"; [ $rc -ge 124 ] && exit $rc
 timeout -k 10 600 python bench.py > gpurun_out/bench_default.log 2> gpurun_out/bench_default.err; rc=$?; echo "[bench] rc=$rc"; [ $rc -ge 124 ] && exit $rc
 timeout -k 10 600 python bench.py --mode faithful --no-cpu > gpurun_out/bench_faithful.log 2> gpurun_out/bench_faithful.err; rc=$?; echo "[bench faithful] rc=$rc"
-for W in c2pp c3 c4 c5 c1 hstorage mnm; do
+for W in ${BENCH_WORKLOADS:-c2pp c3 c4 c5 c1 hstorage mnm}; do
   timeout -k 10 600 python bench.py --no-cpu --workload $W --steps 3 > gpurun_out/bench_$W.log 2> gpurun_out/bench_$W.err; echo "[bench $W] rc=$?"
 done
 # the per-rank work of a strong-scaling run of C2 at N = 8 (128 of the 1024 time rows) on this one GPU

@@ -1483,7 +1483,7 @@ integrate_kernel(const ucf_dev_params P0, int npts, int per_point, int nr, int n
                  const double* __restrict__ tDv, const double* __restrict__ rDv, const int* __restrict__ svv,
                  const double2* __restrict__ tab, int nt, int ir0, double2* __restrict__ state, int* __restrict__ ndone,
                  int* __restrict__ todo, const ucf_dev_params* __restrict__ Pv, int ppp, int pbase, int lsplit,
-                 const double2* __restrict__ ltab, int nrows, int nheadw, int nworkw)
+                 const double2* __restrict__ ltab, int nrows, int nheadw, int nworkw, int* __restrict__ wcount)
 {
     extern __shared__ lds_c lds[];
 #ifdef UCF_K1_ASSUME
@@ -1517,7 +1517,19 @@ integrate_kernel(const ucf_dev_params P0, int npts, int per_point, int nr, int n
     // nothing is left to refill a SIMD, and a wave does not run faster on an emptier SIMD -- in 2^ltail: the drain of the
     // launch lasts as long as a part, not as an item, and only those items pay a part's set-up more than once.
     // (lsplit = lsplit | ltail << 8; nheadw = nhead << lsplit work units of the leading items, nworkw = all of them)
-    for (int wi = blockIdx.x * UCF_IWPB + wv; wi < nworkw; wi += gridDim.x * UCF_IWPB) {
+    // The grid is PERSISTENT -- about as many workgroups as the chip holds -- and every wave draws its work units from one
+    // counter (lane 0's atomic, broadcast): a workgroup's launch, its copy of the tables and the barrier are paid once per
+    // resident wave instead of once per work unit, units are handed out in order (the finer parts of the last items last)
+    // and a wave that ends early simply takes the next one.  Exit: the counter has passed nworkw -- every wave gets there.
+    // (wcount = NULL, diagnostic UCF_PERSIST=0: the grid covers the units, workgroup b takes units 4b .. 4b + 3 and ends)
+    int ustat = blockIdx.x * UCF_IWPB + wv - gridDim.x * UCF_IWPB;
+    auto next_unit = [&]() {
+        if (!wcount) return ustat += gridDim.x * UCF_IWPB;
+        int u = 0;
+        if (lane == 0) u = __hip_atomic_fetch_add(wcount, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return __builtin_amdgcn_readfirstlane(u);
+    };
+    for (int wi = next_unit(); wi < nworkw; wi = next_unit()) {
         const bool tail = wi >= nheadw;
         const int ls = tail ? (lsplit >> 8) : (lsplit & 255), nsplit = 1 << ls;
         const int wj = tail ? wi - nheadw : wi;
@@ -2258,7 +2270,14 @@ static int launch_transform_(const ucf_dev_params& dp, int nwork, int per_point,
         // per workgroup: the sin/cos table + UCF_IWPB waves' accumulators; wlds = the footprint one wave accounts for
         const size_t wlds = (size_t)(dp.R + 1) * dp.nz * UCF_WAVE * sizeof(lds_c) + UCF_SC_ENTRIES * sizeof(lds_c) / UCF_IWPB;
         const size_t ilds = wlds * UCF_IWPB;
-        const dim3 igrid((unsigned)((nworkw + UCF_IWPB - 1) / UCF_IWPB)), iblock(UCF_WAVE * UCF_IWPB);
+        // persistent grid: at most 8 workgroups per CU (more than any register / LDS budget admits; the ones that do not fit
+        // start when others have finished and find the counter exhausted).  UCF_PERSIST=0 (diagnostic): one workgroup per
+        // UCF_IWPB work units, as before round 3's last pass
+        static const bool persist = [] { const char* e = std::getenv("UCF_PERSIST"); return !e || *e != '0'; }();
+        const long long nwg = (nworkw + UCF_IWPB - 1) / UCF_IWPB;
+        const dim3 igrid((unsigned)((persist && nwg > 256 * 8) ? 256 * 8 : nwg)), iblock(UCF_WAVE * UCF_IWPB);
+        int* const d_wcount = d_ndone + 2 * (size_t)nwork + 2 + (size_t)nwork * dp.nz;      // behind the deferred list (finish_kernel)
+        if (persist) (void)hipMemsetAsync(d_wcount, 0, sizeof(int), s);
         // lapTime(p) x constants for every (row of the call's tD, m): rows = the times of a grid / the points of a list.
         // The table lives behind the state of this launch's work items (the caller sized the buffer for it: lt_table_bytes)
         // (LAYOUT 1: the nt times; 3: the nt points of the launch; 0 / 2: the points, or -- a small grid walked point by point,
@@ -2291,7 +2310,7 @@ static int launch_transform_(const ucf_dev_params& dp, int nwork, int per_point,
         ucf_tm_mark(tm, kname, s);                                                                             \
         hipLaunchKernelGGL((integrate_kernel<F, LAYOUT, W, MULTI, FO, L3, NZC, L1>), igrid, iblock, ilds, s, dp, nwork, per_point, nr, nsv, svmin, \
                            d_tD, d_rD, d_sv, (const double2*)d_tab, nt, ir0, (double2*)d_state, d_ndone, d_todo, d_params, ppp, pbase, lsplit | (ltail << 8), \
-                           (const double2*)d_ltab, nrows, nhead << lsplit, (int)nworkw);                                                     \
+                           (const double2*)d_ltab, nrows, nhead << lsplit, (int)nworkw, persist ? d_wcount : (int*)nullptr);                                                     \
     } while (0)
     // launches of ONE depth of the fully penetrating water-table family in the lane = time layout (the headline sweep) run
     // an instantiation that knows nz = 1 at compile time: no depth loop, no running area in LDS (measured on C2: -2.4 %).
@@ -2423,6 +2442,8 @@ static int launch_transform_(const ucf_dev_params& dp, int nwork, int per_point,
         int* const d_defer = d_ndone + 2 * (size_t)nwork + 1;
         const bool two_pass = UCF_FAST && wreg;
         if (two_pass) (void)hipMemsetAsync(d_defer, 0, sizeof(int), s);
+        // (a grid-stride pass with 4 096 ... 65 536 workgroups instead of one per item: 0.92 ms on C2 either way -- the pass is
+        //  bound by the 3.3 GB of state it reads, not by workgroup launches)
 #define UCF_LAUNCH_F(PART, WR)                                                                                 \
     do {                                                                                                       \
         if constexpr (UCF_FAST && (WR)) {                                                                      \
@@ -2519,6 +2540,8 @@ int launch_grid_transposed(const ucf_dev_params& dp, int nt, int nr, int ir0, in
     if (rc) return rc;
     const long long ntl = (long long)nrc * ((nt + UCF_DH_TILE - 1) / UCF_DH_TILE);
     const size_t dlds = 2 * (size_t)dp.np * (UCF_DH_TILE + 1) * sizeof(lds_c) + 2 * UCF_DH_TILE * sizeof(int);
+    // (one workgroup per tile: a capped grid walking the tiles with a stride is SLOWER -- C2 1.34 ms against 1.99 / 1.55 / 1.44 /
+    //  1.37 ms with 2 048 / 4 096 / 8 192 / 16 384 workgroups, measured: a static stride cannot rebalance what the dispatcher does)
     const dim3 dgrid((unsigned)(ntl > 0x7fffffffLL ? 0x7fffffff : ntl));
     if (dp.np <= UCF_WAVE) {
         ucf_tm_mark(tm, UCF_STR(UCF_NS) "::dehoog_tiles_kernel<1, false>", s);
