@@ -48,6 +48,8 @@ for W in ${BENCH_WORKLOADS:-c2pp c3 c4 c5 c1 hstorage mnm}; do
 done
 # the per-rank work of a strong-scaling run of C2 at N = 8 (128 of the 1024 time rows) on this one GPU
 timeout -k 10 300 python bench.py --no-cpu --nt 128 --steps 20 --warmup 2 > gpurun_out/bench_nt128.log 2> gpurun_out/bench_nt128.err; echo "[bench nt128] rc=$?"
+# what each rank of a strong-scaling run at N = 2, 4, 8 REALLY computes: contiguous blocks of the sweep's own time rows, one after the other
+for G in 2 4 8; do timeout -k 10 300 python tools/shard_balance.py c2 $G > gpurun_out/shard_balance_$G.log 2> gpurun_out/shard_balance_$G.err; echo "[shard_balance $G] rc=$? $(tail -c 400 gpurun_out/shard_balance_$G.log)"; done
 # rehearsal of the N > 1 path on this one-GPU box: bench.py starts its own two ranks (both on cuda:0, gloo), strong and weak
 for S in strong weak; do
   UCF_BENCH_ONE_DEVICE=1 UCF_BENCH_BACKEND=gloo timeout -k 10 600 python bench.py --gpus 2 --steps 3 --scaling $S > gpurun_out/bench_gpus2_$S.log 2> gpurun_out/bench_gpus2_$S.err; echo "[bench --gpus 2 $S] rc=$?"
