@@ -445,10 +445,13 @@ UCF_DEV cplx fast_sample_z(const ucf_dev_params& P, const fast_common& S, int iz
     const cplx top = (!FOLD && LAY3 && P.model != 4 && lay == 3) ? S.top3 : S.top;
     // u - top (cosh(eta zD) | exp(eta (zD - 1))) / den  (:85-87 | :89-91); a wave that is on one form only (the usual case)
     // does not select per lane
-    cplx g;
-    if (!S.any_large) g = chz;
-    else if (!S.any_small) g = exz;
-    else g = S.small_eta ? chz : exz;
+    // (one select per lane where a wave has lanes on the exponential form -- small_eta is true in every lane of a wave that has
+    //  none; the three-way form "all small / all large / mixed" came back from the compiler as three selects with uniform masks)
+    cplx g = chz;
+    if (S.any_large) {
+        g = S.small_eta ? chz : exz;
+        asm volatile("" ::: "memory");      // (keeps the block a branch: no select at all in a wave on the cosh form)
+    }
     return cfnma(cmul(top, g), S.inv_den, u);
 }
 
