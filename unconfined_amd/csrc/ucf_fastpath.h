@@ -20,6 +20,14 @@
 
 namespace UCF_NS {
 
+// Marks a block that depends on a WAVE-UNIFORM condition: the block stays a branch.  Without it the compiler turns
+// "uniform ? a : b" into selects on the vector ALU -- one issue slot per dword for a decision the scalar unit has already taken
+// (16 of the 382 VALU instructions per abscissa of the partially penetrating water-table kernel were such selects).
+#define UCF_UNIFORM_BLOCK() asm volatile("" ::: "memory")
+// ... except in the finite-difference kernel, whose node recurrence has no register to spare for the longer live ranges
+// (0 -> 4 spilled VGPRs, +0.7 % on C5 with the marks)
+#define UCF_UNIFORM_BLOCK_F(FAMILY) do { if constexpr ((FAMILY) != 4) UCF_UNIFORM_BLOCK(); } while (0)
+
 struct fprim {
     double ch, sh, ei, sn, cs;    // cosh(x), sinh(x), exp(-|x|), sin(y), cos(y)
 };
@@ -382,21 +390,23 @@ UCF_DEV cplx fast_hantush_z(const ucf_dev_params& P, const fast_common& S, doubl
         if (z2 && FAMILY == 2 && S.any_large) {                  // only exp(eta (zD - 1)) is wanted
             const double c = 1.0 - zD;
             *exz_out = expneg_direct(S.eta.re * c, S.eta.im * c, S.sc);
+            UCF_UNIFORM_BLOCK_F(FAMILY);
         }
         if (need_1z) {
             if (need_chz && S.have_p1 && zD >= 0.0 && zD <= 1.0) p1z = prim_difference(S.p1, pz);     // eta (1 - zD)
             else
             { const double c = 1.0 - zD; p1z = prim(S.eta.re * c, S.eta.im * c, S.sc); }
         }
-        if (!z2 && FAMILY == 2 && S.any_large) *exz_out = pexpneg(p1z);                         // exp(eta*(zD-1))
+        if (!z2 && FAMILY == 2 && S.any_large) { *exz_out = pexpneg(p1z); UCF_UNIFORM_BLOCK_F(FAMILY); } // exp(eta*(zD-1))
         cplx f2c = cmake(0.0, 0.0);
         if (!z2) f2c = cmul(S.ff2, pcosh(p1z));                  // sinh(eta lD1) cosh(eta (1 - zD))
         if (lay == 2 || !LAY3) {
-            if (z1 && z2) return S.th;                                                          // g2 = 0: udp = 1
+            if (z1 && z2) { UCF_UNIFORM_BLOCK_F(FAMILY); return S.th; }                                 // g2 = 0: udp = 1
             cplx num = f2c;
-            if (!z1) num = cadd(cmul(S.ff1, chz), f2c);
+            if (!z1) { num = cadd(cmul(S.ff1, chz), f2c); UCF_UNIFORM_BLOCK_F(FAMILY); }
             g2 = cmul(num, S.inv_she);                                                          // :179-180
             udp = rsub(1.0, g2);                                                                // :192
+            UCF_UNIFORM_BLOCK_F(FAMILY);
         } else {
             // above the screen top: g1 - g2 = cosh(eta (dD1 - zD)) - g2 (:175,196) subtracts two terms of size
             // e^{eta c}/2, c = zD - dD1 >= 0, that agree to e^{-2 eta c}.  With cosh A sinh B = [sinh(A+B) - sinh(A-B)]/2
@@ -410,7 +420,9 @@ UCF_DEV cplx fast_hantush_z(const ucf_dev_params& P, const fast_common& S, doubl
             udp = cmul(num, S.inv_she);
         }
     }
-    return cmul(udp, S.th);                                                                     // :200 (x fast_scale)
+    const cplx res = cmul(udp, S.th);                                                           // :200 (x fast_scale)
+    UCF_UNIFORM_BLOCK_F(FAMILY);         // (the product stays on this path: merged with the early return above it became a select)
+    return res;
 }
 
 template <int FAMILY, bool FOLD = false, bool LAY3 = true, bool LAY1 = true>
