@@ -1477,7 +1477,7 @@ laptime_kernel(const ucf_dev_params P0, int nrows, const double* __restrict__ tD
 // fully penetrating; 5; else 4)
 // UCF_IWPB waves per workgroup: they share nothing but the sin/cos table of sincos_tab_ in LDS (4 KB, copied once from
 // the plan's tables; one barrier, before the work loop); every wave keeps walking its own work items.
-template <int FAMILY, int LAYOUT, int WAVES, bool MULTI, bool FOLD, bool LAY3, int NZC = 0, bool LAY1 = true>      // NZC = 1: one depth per launch, known at compile time
+template <int FAMILY, int LAYOUT, int WAVES, bool MULTI, bool FOLD, bool LAY3, int NZC = 0, bool LAY1 = true, bool NOFOLD = false>      // NZC = 1: one depth per launch, known at compile time
 __global__ void __launch_bounds__(UCF_WAVE * UCF_IWPB, WAVES)
 integrate_kernel(const ucf_dev_params P0, int npts, int per_point, int nr, int nsv, int svmin,
                  const double* __restrict__ tDv, const double* __restrict__ rDv, const int* __restrict__ svv,
@@ -1587,14 +1587,14 @@ integrate_kernel(const ucf_dev_params P0, int npts, int per_point, int nr, int n
             const bool ts = n < N;
             F.sc.salt = n;
             if (__builtin_amdgcn_ballot_w64(!fast_eta<EF>(P, LC, aa.x, F)) != 0) break;          // (every lane is live here)
-            fast_common_terms<EF, FOLD, LAY3, LAY1>(P, LC, aa.x, need_lay1, F, need_lay3, need_lay12);
+            fast_common_terms<EF, FOLD, LAY3, LAY1, NOFOLD>(P, LC, aa.x, need_lay1, F, need_lay3, need_lay12);
             const int n1 = n + 1;
             int tz = __builtin_ctz(n1);
             if (tz > R - 1) tz = R - 1;
             for (int z = 0; z < nz; z++) {
                 // val = a*J0(a rD) * f(a,p,z) [* lapTime(p): at the end]                         (lhs.f90:118)
                 // (Gauss-Lobatto part: aa.y carries the node's weight, abscissa_kernel)
-                const cplx fz = fast_sample_z<EF, FOLD, LAY3, LAY1>(P, F, z);
+                const cplx fz = fast_sample_z<EF, FOLD, LAY3, LAY1, NOFOLD>(P, F, z);
                 if (ts) {
                     const cplx val = rscale(aa.y, fz);
                     // tanh-sinh on [0, arg]: abscissa n+1 belongs to level j when 2^(R-j) divides it  (driver.f90:129-157)
@@ -2301,14 +2301,14 @@ static int launch_transform_(const ucf_dev_params& dp, int nwork, int per_point,
 #undef UCF_LAUNCH_LT
         }
         static const bool nzc2_on = [] { const char* e = std::getenv("UCF_NZC2"); return !e || *e != '0'; }();      // diagnostic: 0 = off
-#define UCF_LAUNCH_I4(F, W, FO, L3, NZC, L1)                                                                       \
+#define UCF_LAUNCH_I4(F, W, FO, L3, NZC, L1, NF)                                                                     \
     do {                                                                                                       \
         const size_t ilds = ((size_t)((NZC) ? dp.R : dp.R + 1) * dp.nz * UCF_WAVE * sizeof(lds_c)) * UCF_IWPB + UCF_SC_ENTRIES * sizeof(lds_c); \
         if (ilds > 64 * 1024)                                                                                  \
-            (void)hipFuncSetAttribute((const void*)integrate_kernel<F, LAYOUT, W, MULTI, FO, L3, NZC, L1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ilds); \
-        std::snprintf(kname, sizeof(kname), UCF_STR(UCF_NS) "::integrate_kernel<%d, %d, %d, %s, %s, %s, %d, %s>", F, LAYOUT, W, MULTI ? "true" : "false", FO ? "true" : "false", L3 ? "true" : "false", NZC, L1 ? "true" : "false"); \
+            (void)hipFuncSetAttribute((const void*)integrate_kernel<F, LAYOUT, W, MULTI, FO, L3, NZC, L1, NF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ilds); \
+        std::snprintf(kname, sizeof(kname), UCF_STR(UCF_NS) "::integrate_kernel<%d, %d, %d, %s, %s, %s, %d, %s, %s>", F, LAYOUT, W, MULTI ? "true" : "false", FO ? "true" : "false", L3 ? "true" : "false", NZC, L1 ? "true" : "false", NF ? "true" : "false"); \
         ucf_tm_mark(tm, kname, s);                                                                             \
-        hipLaunchKernelGGL((integrate_kernel<F, LAYOUT, W, MULTI, FO, L3, NZC, L1>), igrid, iblock, ilds, s, dp, nwork, per_point, nr, nsv, svmin, \
+        hipLaunchKernelGGL((integrate_kernel<F, LAYOUT, W, MULTI, FO, L3, NZC, L1, NF>), igrid, iblock, ilds, s, dp, nwork, per_point, nr, nsv, svmin, \
                            d_tD, d_rD, d_sv, (const double2*)d_tab, nt, ir0, (double2*)d_state, d_ndone, d_todo, d_params, ppp, pbase, lsplit | (ltail << 8), \
                            (const double2*)d_ltab, nrows, nhead << lsplit, (int)nworkw, persist ? d_wcount : (int*)nullptr);                                                     \
     } while (0)
@@ -2326,23 +2326,33 @@ static int launch_transform_(const ucf_dev_params& dp, int nwork, int per_point,
 #ifndef UCF_NZC2
 #define UCF_NZC2(F, FO) ((LAYOUT == 1 || LAYOUT == 3) ? 2 : 0)
 #endif
-#define UCF_LAUNCH_I3(F, W, FO, L3, L1)                                                                        \
+#define UCF_LAUNCH_I3(F, W, FO, L3, L1, NF)                                                                    \
     do {                                                                                                       \
-        if (UCF_NZC(F, FO) && dp.nz == 1) UCF_LAUNCH_I4(F, W, FO, L3, UCF_NZC(F, FO), L1);                     \
-        else if (UCF_NZC2(F, FO) && dp.nz == 2 && nzc2_on) UCF_LAUNCH_I4(F, W, FO, L3, UCF_NZC2(F, FO), L1);    \
-        else UCF_LAUNCH_I4(F, W, FO, L3, 0, L1);                                                               \
+        if (UCF_NZC(F, FO) && dp.nz == 1) UCF_LAUNCH_I4(F, W, FO, L3, UCF_NZC(F, FO), L1, NF);                 \
+        else if (UCF_NZC2(F, FO) && dp.nz == 2 && nzc2_on) UCF_LAUNCH_I4(F, W, FO, L3, UCF_NZC2(F, FO), L1, NF); \
+        else UCF_LAUNCH_I4(F, W, FO, L3, 0, L1, NF);                                                           \
     } while (0)
         // a depth above the screen top anywhere in the call (in any plan of a parameter batch)?
         const bool lay3 = dp.any_lay3 != 0;
         // ... below the screen bottom?  Three instantiations of an unfolded kernel: every layer / beside and below the screen /
         // beside the screen only (the usual piezometer or observation well)
         const bool lay1 = dp.any_lay1 != 0;
-#define UCF_LAUNCH_FOLD(F, W) UCF_LAUNCH_I3(F, W, true, false, true)
+#define UCF_LAUNCH_FOLD(F, W) UCF_LAUNCH_I3(F, W, true, false, true, false)
+        // neither screen term folds (d > 0 and l < b: the usual partially penetrating well) -- known at compile time in an
+        // instantiation of its own (NOFOLD, ucf_fastpath.h); a plan that folds exactly one term, and a parameter batch with
+        // such a plan or a fully penetrating one in it, run the general one.  UCF_NOFOLD=0 (diagnostic): always the general one
+        static const bool nofold_on = [] { const char* e = std::getenv("UCF_NOFOLD"); return !e || *e != '0'; }();
+        const bool nofold = nofold_on && !dp.any_fold;
+#define UCF_LAUNCH_UNF_(F, W, NF)                                                                              \
+    do {                                                                                                       \
+        if (lay3) UCF_LAUNCH_I3(F, W, false, true, true, NF);                                                  \
+        else if (lay1) UCF_LAUNCH_I3(F, W, false, false, true, NF);                                            \
+        else UCF_LAUNCH_I3(F, W, false, false, false, NF);                                                     \
+    } while (0)
 #define UCF_LAUNCH_UNF(F, W)                                                                                   \
     do {                                                                                                       \
-        if (lay3) UCF_LAUNCH_I3(F, W, false, true, true);                                                      \
-        else if (lay1) UCF_LAUNCH_I3(F, W, false, false, true);                                                \
-        else UCF_LAUNCH_I3(F, W, false, false, false);                                                         \
+        if (nofold) { UCF_LAUNCH_UNF_(F, W, true); break; }                                                    \
+        UCF_LAUNCH_UNF_(F, W, false);                                                                          \
     } while (0)
         // fully penetrating pumping well (every plan of a parameter batch must be): the screen terms are compiled out
         const bool fold = dp.fold_dD && dp.fold_lD1 && !MULTI;
@@ -2384,6 +2394,7 @@ static int launch_transform_(const ucf_dev_params& dp, int nwork, int per_point,
         }
 #undef UCF_LAUNCH_FOLD
 #undef UCF_LAUNCH_UNF
+#undef UCF_LAUNCH_UNF_
 #undef UCF_LAUNCH_I3
 #undef UCF_LAUNCH_I4
     }

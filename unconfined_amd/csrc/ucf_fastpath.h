@@ -205,11 +205,15 @@ UCF_DEV bool fast_eta(const ucf_dev_params& P, const lane_consts& L, double a, f
 
 // z-independent part (after fast_eta said yes for every lane of the wave)
 // FOLD: the plan is known to be fully penetrating (fold_dD and fold_lD1), so that none of the screen terms is even
-// compiled in (the launcher picks the instantiation; FOLD = false handles every plan)
+// compiled in (the launcher picks the instantiation; FOLD = false handles every plan).  NOFOLD: the plan is known to fold
+// NEITHER screen term (d > 0 and l < b, the usual partially penetrating well): the run-time tests of the two flags, the
+// values a folded term would have taken and the copies where the two cases join are not compiled in (round 3, last pass:
+// C2pp 81.8 -> 77.3 ms, C3 106.7 -> 99.9, C4 219.8 -> 208.6, Hantush with storage 66.8 -> 60.8; a plan that folds exactly
+// one of the two terms, and every parameter batch, runs the general instantiation)
 // LAY3 = false: the launcher knows that no depth of the call lies above the screen top; LAY1 = false: none below its bottom
 // (the usual piezometer beside the screen: the terms of the layer below -- exp(-eta), g3 -- are then not even allocated:
 //  18 -> 14 spilled VGPRs in the partially penetrating water-table kernel, C2pp 87.9 -> 85.7 ms, C4 236.2 -> 230.3)
-template <int FAMILY, bool FOLD = false, bool LAY3 = true, bool LAY1 = true>
+template <int FAMILY, bool FOLD = false, bool LAY3 = true, bool LAY1 = true, bool NOFOLD = false>
 UCF_DEV void fast_common_terms(const ucf_dev_params& P, const lane_consts& L, double a, bool need_lay1_in, fast_common& S,
                                bool need_lay3_in = false, bool need_lay12 = true)
 {
@@ -230,7 +234,7 @@ UCF_DEV void fast_common_terms(const ucf_dev_params& P, const lane_consts& L, do
         return;
     }
     const bool hantush = !(FAMILY == 2 && P.model == 4);
-    const bool z1 = FOLD || P.fold_dD != 0, z2 = FOLD || P.fold_lD1 != 0;
+    const bool z1 = FOLD || (!NOFOLD && P.fold_dD != 0), z2 = FOLD || (!NOFOLD && P.fold_lD1 != 0);
     const bool need_lay1 = (FOLD || !LAY1) ? false : need_lay1_in;   // a fully penetrating screen has no layer below it
     const bool need_lay3 = (FOLD || !LAY3) ? false : need_lay3_in;   // ... nor above it
     // the water-table closure switches to its exponential form at Re(eta) >= maxexp (:84) and then needs neither
@@ -369,11 +373,11 @@ UCF_DEV bool fast_prepare(const ucf_dev_params& P, const lane_consts& L, double 
 }
 
 // Hantush factor at depth zD (:133-202); chz = cosh(eta*zD) is returned for the closure
-template <int FAMILY, bool FOLD = false, bool LAY3 = true, bool LAY1 = true>
+template <int FAMILY, bool FOLD = false, bool LAY3 = true, bool LAY1 = true, bool NOFOLD = false>
 UCF_DEV cplx fast_hantush_z(const ucf_dev_params& P, const fast_common& S, double zD, int lay_in, cplx* chz_out,
                             cplx* exz_out)
 {
-    const bool z1 = FOLD || P.fold_dD != 0, z2 = FOLD || P.fold_lD1 != 0;
+    const bool z1 = FOLD || (!NOFOLD && P.fold_dD != 0), z2 = FOLD || (!NOFOLD && P.fold_lD1 != 0);
     const int lay = (FOLD || (!LAY1 && lay_in == 1)) ? 2 : lay_in;      // (FOLD: everything is beside the screen)
     const bool need_chz = (lay == 1) || !z1 || (FAMILY == 2 && S.any_small) || FAMILY == 4;
     cplx chz = cmake(1.0, 0.0);
@@ -425,7 +429,7 @@ UCF_DEV cplx fast_hantush_z(const ucf_dev_params& P, const fast_common& S, doubl
     return res;
 }
 
-template <int FAMILY, bool FOLD = false, bool LAY3 = true, bool LAY1 = true>
+template <int FAMILY, bool FOLD = false, bool LAY3 = true, bool LAY1 = true, bool NOFOLD = false>
 UCF_DEV cplx fast_sample_z(const ucf_dev_params& P, const fast_common& S, int iz)
 {
     const double zD = P.zD[iz];
@@ -436,9 +440,9 @@ UCF_DEV cplx fast_sample_z(const ucf_dev_params& P, const fast_common& S, int iz
         const cplx cz = pcosh(prim<true>(S.eta.re * zD, S.eta.im * zD, S.sc));
         return cfma(S.th, cmul(S.mn_uod, cz), S.th);                                            // :437-439 (x fast_scale)
     }
-    if (FAMILY == 1) return fast_hantush_z<1, FOLD, LAY3, LAY1>(P, S, zD, lay, &chz, &exz);
+    if (FAMILY == 1) return fast_hantush_z<1, FOLD, LAY3, LAY1, NOFOLD>(P, S, zD, lay, &chz, &exz);
     if (FAMILY == 4) {
-        const cplx sH = fast_hantush_z<4, FOLD, LAY3, LAY1>(P, S, zD, lay, &chz, &exz);
+        const cplx sH = fast_hantush_z<4, FOLD, LAY3, LAY1, NOFOLD>(P, S, zD, lay, &chz, &exz);
         if (!FOLD && LAY3 && lay == 3) return S.fd_use3 ? cadd(sH, cmul(S.fd_s13, chz)) : sH;
         return S.fd_use ? cadd(sH, cmul(S.fd_s1, chz)) : sH;                                    // :522-525
     }
@@ -448,7 +452,7 @@ UCF_DEV cplx fast_sample_z(const ucf_dev_params& P, const fast_common& S, int iz
         if (S.any_small) chz = pcosh(prim(S.eta.re * zD, S.eta.im * zD, S.sc));
         if (S.any_large) { const double c = 1.0 - zD; exz = expneg_direct(S.eta.re * c, S.eta.im * c, S.sc); }
     } else {
-        u = fast_hantush_z<2, FOLD, LAY3, LAY1>(P, S, zD, lay, &chz, &exz);
+        u = fast_hantush_z<2, FOLD, LAY3, LAY1, NOFOLD>(P, S, zD, lay, &chz, &exz);
         if (LAY1 && S.any_large && lay == 1) { const double c = 1.0 - zD; exz = expneg_direct(S.eta.re * c, S.eta.im * c, S.sc); }
     }
 #ifdef UCF_SINGLE_RCP
