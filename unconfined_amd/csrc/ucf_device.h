@@ -1586,7 +1586,7 @@ integrate_kernel(const ucf_dev_params P0, int npts, int per_point, int nr, int n
             const double2 nxt = row[n + 1 < nabs ? n + 1 : n];
             const bool ts = n < N;
             F.sc.salt = n;
-            if (__builtin_amdgcn_ballot_w64(!fast_eta<EF>(P, LC, aa.x, F)) != 0) break;          // (every lane is live here)
+            if (!fast_eta_wave<EF>(P, LC, aa.x, F)) break;                                       // (every lane is live here)
             fast_common_terms<EF, FOLD, LAY3, LAY1, NOFOLD>(P, LC, aa.x, need_lay1, F, need_lay3, need_lay12);
             const int n1 = n + 1;
             int tz = __builtin_ctz(n1);

@@ -202,6 +202,21 @@ UCF_DEV bool fast_eta(const ucf_dev_params& P, const lane_consts& L, double a, f
     // (three compares and two scalar ANDs; the short-circuit form rebuilt the flag through a select)
     return (S.eta.re <= P.fast_eta_max) & (q.re > 0.0) & (fabs(S.eta.im) < P.fast_im_max);
 }
+// the same for a whole wave: true if EVERY lane may take the fast evaluation.  One ballot per compare and the scalar unit's OR
+// (the ballot of the combined per-lane flag came back as flag -> 0 / 1 in a VGPR -> compare again: two VALU instructions per
+// abscissa for nothing)
+template <int FAMILY>
+UCF_DEV bool fast_eta_wave(const ucf_dev_params& P, const lane_consts& L, double a, fast_common& S)
+{
+    (void)fast_eta<FAMILY>(P, L, a, S);
+    const cplx q = caddr(L.p, a * a);
+    unsigned long long bad = __builtin_amdgcn_ballot_w64(!(q.re > 0.0));
+    if (FAMILY != 0) {
+        bad |= __builtin_amdgcn_ballot_w64(!(S.eta.re <= P.fast_eta_max));
+        bad |= __builtin_amdgcn_ballot_w64(!(fabs(S.eta.im) < P.fast_im_max));
+    }
+    return bad == 0;
+}
 
 // z-independent part (after fast_eta said yes for every lane of the wave)
 // FOLD: the plan is known to be fully penetrating (fold_dD and fold_lD1), so that none of the screen terms is even
