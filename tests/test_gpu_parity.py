@@ -636,6 +636,68 @@ np.savez(sys.argv[2], **out)
 """
 
 
+def test_general_instantiation_stays_under_the_gates(tmp_path):
+    """A plan that folds neither screen term (d > 0, l < b) runs the NOFOLD instantiations of the unfolded kernels since the last
+    pass of round 3; the GENERAL instantiation is left with plans that fold exactly one term and with mixed parameter batches.
+    It must not drop out of the parity net: the end-to-end gates of the partially penetrating decks (point list and grid
+    entry, fast flavour) once more in a child process with UCF_NOFOLD=0, and one deck of each family general against NOFOLD"""
+    import subprocess, sys
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, UCF_NOFOLD="0", UCF_PARITY_OUT=str(tmp_path / "parity_general.json"))
+    sel = ("(end_to_end_vs_reference_outputs or end_to_end_vs_binary128_truth) and fast and "
+           "(neuman74_partpen or c4_malama_partpen or c3_moench or hantush_lay2 or hstorage_partpen_lay2 or mishra_fd30 or c5_mishra_fd64)")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-q", "-x", "-m", "gpu",
+                        "-p", "no:cacheprovider", "--no-header", "-k", sel], env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
+    # the two instantiations against each other: same formulas, other contractions -- the fast flavour's rounding noise
+    res = {}
+    for tag, e in (("nofold", {}), ("general", {"UCF_NOFOLD": "0"})):
+        out = str(tmp_path / f"{tag}.npz")
+        ee = {k: v for k, v in os.environ.items() if k != "UCF_NOFOLD"}
+        ee.update(e)
+        subprocess.run([sys.executable, "-c", _NOFOLD_SCRIPT, root, out], check=True, env=ee, timeout=600)
+        res[tag] = np.load(out)
+    ran = {str(x) for x in res["nofold"]["kernels"]} | {str(x) for x in res["general"]["kernels"]}
+    assert any(k.endswith(", true>") for k in ran if "integrate_kernel" in k), ran        # NOFOLD did run ...
+    assert all(not k.endswith(", true>") for k in (str(x) for x in res["general"]["kernels"]) if "integrate_kernel" in k)     # ... and not under UCF_NOFOLD=0
+    for k in res["nofold"].files:
+        if k == "kernels":
+            continue
+        a, b = res["nofold"][k], res["general"][k]
+        assert np.array_equal(np.isnan(a), np.isnan(b)), k
+        fin = np.isfinite(a)
+        scale = np.abs(b[fin]).max()
+        # (h to 1e-6; the log-derivative, whose inversion amplifies the Laplace-space rounding 1e2 x more -- DESIGN.md section 2,
+        #  c(row) -- to 1e-4: both instantiations pass the gates against the reference in their own right, above)
+        assert (np.abs(a[fin] - b[fin]) / np.maximum(np.abs(b[fin]), 1e-4 * scale)).max() < (1e-4 if k.endswith("_dh") else 1e-6), k
+
+
+_NOFOLD_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+from golden_util import load_deck
+from unconfined_amd import engine
+out = {}; kernels = set()
+for name in ("hantush_lay2", "neuman74_partpen", "c4_malama_partpen", "hstorage_partpen_lay2", "mishra_fd30"):
+    dk, ts, P = load_deck(name)
+    pl = engine.Plan(P, mode="fast")
+    pl.set_timing(True)
+    for nz, zD in ((1, np.array([0.6])), (2, np.array([0.3, 0.93]))):
+        zl = pl.zlay(zD)
+        tD = np.logspace(-1, 4, 128); rD = np.array([0.11, 0.7, 3.0, 9.0])
+        h, dh = pl.drawdown_grid(tD, pl.split_vector(tD), rD, zD, zl)
+        kernels |= {n for n, ms, cnt in pl.kernel_times()}
+        out["%s_nz%d_h" % (name, nz)] = h; out["%s_nz%d_dh" % (name, nz)] = dh
+    pl.close()
+out["kernels"] = np.array(sorted(kernels))
+np.savez(sys.argv[2], **out)
+"""
+
+
 def test_point_list_layouts_same_bits_faithful(tmp_path):
     """a list of 400 arbitrary points in the lane = point and in the lane = Laplace-sample layout: the faithful
     flavour gives the same bits (six models, all layers)"""
