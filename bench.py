@@ -13,8 +13,9 @@ One "step" = one pass of the hot path over the whole synthetic sweep that is res
 N > 1: one process per GPU over RCCL.  Under torch.distributed.run (RANK / WORLD_SIZE in the
 environment) this file is a rank; started plainly with --gpus N it launches its N ranks itself
 (fresh child processes, before anything here touches a GPU) and fails if RCCL does not see N ranks.
-  --scaling weak (default)    every rank owns a full nt x nr sweep (the metric's 1024 x 256 on C2) of its own block of
-                              radii, nt x nr*N in all: the points are independent, per-GPU work is fixed as N grows.
+  --scaling weak (default)    every rank owns a full nt x nr sweep (the metric's 1024 x 256 on C2) over every N-th radius
+                              of an nt x nr*N sweep (cyclic: each rank spans rD = 0.1 ... 10 and costs the same): the points
+                              are independent, per-GPU work is fixed as N grows.
   --scaling strong            the FIXED sweep of the workload (C2 1024x256, C4 4096x1024, ...) is cut into N contiguous
                               blocks of time rows (ucf_shard_rows: the reference's i loop, driver.f90:100); every
                               rank computes its rows in place in the full-size result arrays and one in-place
@@ -334,9 +335,11 @@ def worker(args):
                 else:
                     to_host_gather(d_full[a], lambda hst: sharding.allgather_rows_(hst, nt, row, world, rank))
 
-    # ---- weak scaling: nt x (nr * world) sweep, every rank a block of nr radii
+    # ---- weak scaling: nt x (nr * world) sweep, every rank nr of its radii -- every world-th one (cyclic): each rank's sweep
+    # spans the whole range rD = 0.1 ... 10 like the metric's own, so the ranks cost the same (contiguous blocks of radii do not:
+    # the cosh form of the closure at large radii costs 1.3 x the exponential form at small ones, tools/shard_balance.py)
     rD_all = 10.0 ** engine.linspace(-1.0, 1.0, nr * world)
-    d_rD_mine = torch.from_numpy(np.ascontiguousarray(rD_all[rank * nr:(rank + 1) * nr])).to(dev)
+    d_rD_mine = torch.from_numpy(np.ascontiguousarray(rD_all[rank::world])).to(dev)
     d_out = d_all = None
 
     def alloc_weak():
@@ -521,7 +524,7 @@ def worker(args):
                                f"ord={dk.ord} ({D.nabs} abscissae, {samples_per_pt} samples/point)",
                    "points_per_step": pts_main, "points_per_gpu": pts_launch, "mode": args.mode, "layout": args.layout,
                    "partition": ("contiguous blocks of time rows (ucf_shard_rows), in-place all-gather of h and dh" if args.scaling == "strong"
-                                 else "one block of radii per rank, all-gather of [h; dh]") + f", one rank per GPU, backend {backend if world > 1 else 'none'}",
+                                 else "every world-th radius per rank (cyclic), all-gather of [h; dh]") + f", one rank per GPU, backend {backend if world > 1 else 'none'}",
                    "gather": main_gather,
                    "launcher": "self (bench.py spawned its ranks)" if os.environ.get("UCF_BENCH_SELF_LAUNCHED") else ("torch.distributed.run" if world > 1 else "single process"),
                    "build_id": build_id, "results_finite_and_gather_consistent": ok},
