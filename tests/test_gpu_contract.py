@@ -576,11 +576,12 @@ def test_results_do_not_depend_on_how_work_items_are_cut(tmp_path):
             ("quarters", {"UCF_NSPLIT": "1", "UCF_TAIL_LSPLIT": "2", "UCF_TAIL_ITEMS": "100000000"}),
             ("eighths", {"UCF_NSPLIT": "8"}),
             ("mixed", {"UCF_NSPLIT": "1", "UCF_TAIL_LSPLIT": "3", "UCF_TAIL_ITEMS": "37"}),
+            ("static", {"UCF_PERSIST": "0"}),           # one workgroup per four work units instead of the persistent grid
             ("default", {}))
     res = {}
     for tag, env in cuts:
         out = str(tmp_path / f"{tag}.npz")
-        e = {k: v for k, v in os.environ.items() if k not in ("UCF_NSPLIT", "UCF_TAIL_LSPLIT", "UCF_TAIL_ITEMS")}
+        e = {k: v for k, v in os.environ.items() if k not in ("UCF_NSPLIT", "UCF_TAIL_LSPLIT", "UCF_TAIL_ITEMS", "UCF_PERSIST")}
         e.update(env)
         subprocess.run([sys.executable, "-c", _PARTS_SCRIPT, root, out], check=True, env=e, timeout=600)
         res[tag] = np.load(out)
