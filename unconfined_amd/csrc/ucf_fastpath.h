@@ -224,7 +224,10 @@ UCF_DEV bool fast_eta_wave(const ucf_dev_params& P, const lane_consts& L, double
 // NEITHER screen term (d > 0 and l < b, the usual partially penetrating well): the run-time tests of the two flags, the
 // values a folded term would have taken and the copies where the two cases join are not compiled in (round 3, last pass:
 // C2pp 81.8 -> 77.3 ms, C3 106.7 -> 99.9, C4 219.8 -> 208.6, Hantush with storage 66.8 -> 60.8; a plan that folds exactly
-// one of the two terms, and every parameter batch, runs the general instantiation)
+// one of the two terms, and a parameter batch with such a plan in it, runs the general instantiation).  A NOFOLD launch also knows that its
+// plans carry the Hantush factor (no model 4 -- Neuman 1972 has no screen -- among them: dp.any_fold covers both): the run-time
+// choice between "Hantush factor" and "Theis factor" and the copies where the two join are not compiled in either
+// (C2pp 77.2 -> 75.3 ms, C3 100.6 -> 96.2, C4 209.0 -> 203.7)
 // LAY3 = false: the launcher knows that no depth of the call lies above the screen top; LAY1 = false: none below its bottom
 // (the usual piezometer beside the screen: the terms of the layer below -- exp(-eta), g3 -- are then not even allocated:
 //  18 -> 14 spilled VGPRs in the partially penetrating water-table kernel, C2pp 87.9 -> 85.7 ms, C4 236.2 -> 230.3)
@@ -248,7 +251,7 @@ UCF_DEV void fast_common_terms(const ucf_dev_params& P, const lane_consts& L, do
         S.mn_uod = cmul(u, cinv_auto(Delta0));
         return;
     }
-    const bool hantush = !(FAMILY == 2 && P.model == 4);
+    const bool hantush = NOFOLD || !(FAMILY == 2 && P.model == 4);      // (a NOFOLD launch holds no model-4 plan: launch_transform_)
     const bool z1 = FOLD || (!NOFOLD && P.fold_dD != 0), z2 = FOLD || (!NOFOLD && P.fold_lD1 != 0);
     const bool need_lay1 = (FOLD || !LAY1) ? false : need_lay1_in;   // a fully penetrating screen has no layer below it
     const bool need_lay3 = (FOLD || !LAY3) ? false : need_lay3_in;   // ... nor above it
@@ -462,7 +465,7 @@ UCF_DEV cplx fast_sample_z(const ucf_dev_params& P, const fast_common& S, int iz
         return S.fd_use ? cadd(sH, cmul(S.fd_s1, chz)) : sH;                                    // :522-525
     }
     cplx u;
-    if (P.model == 4) {
+    if (!NOFOLD && P.model == 4) {
         u = S.th;
         if (S.any_small) chz = pcosh(prim(S.eta.re * zD, S.eta.im * zD, S.sc));
         if (S.any_large) { const double c = 1.0 - zD; exz = expneg_direct(S.eta.re * c, S.eta.im * c, S.sc); }
@@ -471,9 +474,9 @@ UCF_DEV cplx fast_sample_z(const ucf_dev_params& P, const fast_common& S, int iz
         if (LAY1 && S.any_large && lay == 1) { const double c = 1.0 - zD; exz = expneg_direct(S.eta.re * c, S.eta.im * c, S.sc); }
     }
 #ifdef UCF_SINGLE_RCP
-    if (FOLD || P.model == 4) return cmul(csub(S.den, S.small_eta ? chz : exz), S.inv_den);
+    if (FOLD || (!NOFOLD && P.model == 4)) return cmul(csub(S.den, S.small_eta ? chz : exz), S.inv_den);
 #endif
-    const cplx top = (!FOLD && LAY3 && P.model != 4 && lay == 3) ? S.top3 : S.top;
+    const cplx top = (!FOLD && LAY3 && (NOFOLD || P.model != 4) && lay == 3) ? S.top3 : S.top;
     // u - top (cosh(eta zD) | exp(eta (zD - 1))) / den  (:85-87 | :89-91); a wave that is on one form only (the usual case)
     // does not select per lane
     // (one select per lane where a wave has lanes on the exponential form -- small_eta is true in every lane of a wave that has

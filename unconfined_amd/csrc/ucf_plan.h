@@ -21,7 +21,7 @@ struct ucf_dev_params {
     int tab_premul;        // the abscissa table's Gauss-Lobatto entries carry their quadrature weight (fast flavour; abscissa_kernel)
     int nj0z, any_lay3;    // any_lay3: some depth of the launch (of any plan of a parameter batch) lies above the screen top
     int any_lay1;          // ... below the screen bottom
-    int any_fold;          // some plan of the launch folds a screen term (fold_dD or fold_lD1): 0 = the NOFOLD instantiations may run
+    int any_fold;          // some plan of the launch folds a screen term (fold_dD or fold_lD1) or is model 4 (no screen terms): 0 = the NOFOLD instantiations may run
     int nz_out, z_off;     // depths of the whole call / offset of this launch's chunk: out index = pt*nz_out + z_off + z
     double timePar[2];
     double kappa, alphaD, beta;
